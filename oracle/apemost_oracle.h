@@ -1,0 +1,176 @@
+/*
+ * apemost_oracle.h -- CPU restatement of APEMoST's parallel-tempering hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under apemost_amd/, include/ or the host
+ * library may include, link or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / the timed
+ * CPU baseline -- never as the product path.
+ *
+ * Pinning status (see oracle/README.md):
+ *   pinned   : mt19937 stream (GSL rng KATs), simplesin likelihood (manual eval
+ *              KAT), params/data parser fixtures, gsl_sf_log KATs, mod_double KATs.
+ *   unpinned : sampler trajectories, calibration results, swap sequences -- the
+ *              reference holds no fixture for them and cannot be built here
+ *              (GSL absent).  "parity unpinned" for those.
+ *
+ * Every function cites the reference file:line (relative to the APEMoST tree)
+ * whose behaviour it restates.
+ */
+#ifndef APEMOST_ORACLE_H
+#define APEMOST_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- models (apps/<model>.c) ------------------------------------------- */
+enum {
+    ORC_MODEL_SIMPLESIN = 0,  /* apps/simplesin.c:12-38, n_par = 4          */
+    ORC_MODEL_PULSE = 1,      /* apps/pulse.c:12-54, n_par = 2 + 2*modes    */
+    ORC_MODEL_PULSE_VROT = 2, /* apps/pulse_vrot.c:12-65, n_par = 7         */
+    ORC_MODEL_SINE3 = 3       /* own 10-parameter model, SURVEY N3           */
+};
+
+/* ---- beta ladders (src/parallel_tempering_beta.c:53-83) ---------------- */
+enum {
+    ORC_LADDER_CHEBYSHEV_BETA = 0,
+    ORC_LADDER_EQUIDISTANT_BETA = 1,
+    ORC_LADDER_EQUIDISTANT_TEMPERATURE = 2,
+    ORC_LADDER_CHEBYSHEV_TEMPERATURE = 3,
+    ORC_LADDER_EQUIDISTANT_STEPWIDTH = 4,
+    ORC_LADDER_CHEBYSHEV_STEPWIDTH = 5,
+    ORC_LADDER_HOT_CHAINS = 6
+};
+
+/* ---- RNG ----------------------------------------------------------------
+ * ORC_RNG_GLOBAL_MT : the reference's single process-global gsl mt19937
+ *                     (src/mcmc.c:27-35), consumed in program order.
+ * ORC_RNG_STREAMS   : counter-based Philox4x32-10 streams laid out the way the
+ *                     device engine uses rocRAND: stream (chain c, slot s) has
+ *                     subsequence c*256+s; slot p<n_par feeds the proposal of
+ *                     parameter p, slot n_par feeds the accept test; the swap
+ *                     stream is subsequence 2^63, position 4*round.
+ */
+enum { ORC_RNG_GLOBAL_MT = 0, ORC_RNG_STREAMS = 1 };
+
+typedef struct {
+    uint32_t mt[624];
+    int mti;
+} orc_mt19937;
+
+void orc_mt_seed(orc_mt19937 *g, unsigned long seed);
+uint32_t orc_mt_next(orc_mt19937 *g);
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* n-th 32-bit output of rocRAND's philox4x32_10 engine (seed, subsequence, offset=n) */
+uint32_t orc_philox_at(uint64_t seed, uint64_t subsequence, uint64_t n);
+
+#define ORC_STREAMS_PER_CHAIN 256
+#define ORC_SWAP_SUBSEQUENCE 0x8000000000000000ULL
+
+typedef struct {
+    int kind;            /* ORC_RNG_* */
+    orc_mt19937 mt;      /* GLOBAL_MT state */
+    uint64_t seed;       /* STREAMS: philox key */
+    uint64_t *offsets;   /* STREAMS: [n_chain][n_par+1] draws consumed per stream */
+    uint64_t round;      /* STREAMS: swap-stream position */
+    uint64_t draws;      /* statistics: total 32-bit draws consumed */
+} orc_rng;
+
+/* ---- ladder state: structure of arrays, same layout as the device ------- */
+typedef struct {
+    int n_chain;            /* chains held here */
+    int n_par;
+    int model;
+    int n_data, n_cols;
+    int64_t chain_offset;   /* global index of local chain 0 (sharded ladders) */
+    const double *data;     /* row-major [n_data][n_cols], shared by all chains */
+    double sigma;           /* SIGMA (simplesin.c:8-10), default 0.5 */
+    double hmin;            /* HMIN (pulse.c:8-10), default 1e-6 */
+    /* per chain */
+    double *params;         /* [n_chain][n_par] */
+    double *params_best;    /* [n_chain][n_par] */
+    double *step;           /* [n_chain][n_par] */
+    double *pmin;           /* [n_chain][n_par] */
+    double *pmax;           /* [n_chain][n_par] */
+    uint64_t *params_accepts; /* [n_chain][n_par] */
+    uint64_t *params_rejects; /* [n_chain][n_par] */
+    double *beta;           /* [n_chain] */
+    double *prob;           /* [n_chain] */
+    double *prior;          /* [n_chain] */
+    double *prob_best;      /* [n_chain] */
+    uint64_t *accept;       /* [n_chain] */
+    uint64_t *reject;       /* [n_chain] */
+    uint64_t *n_iter;       /* [n_chain] */
+    uint64_t *swapcount;    /* [n_chain] */
+} orc_state;
+
+/* calibration knobs (src/define_defaults.h:24-86, src/markov_chain.h:25-32) */
+typedef struct {
+    unsigned int burn_in_iterations; /* BURN_IN_ITERATIONS 10000 */
+    double rat_limit;                /* desired_acceptance_rate argument, 0.5 */
+    double target_global;            /* TARGET_ACCEPTANCE_RATE macro, 0.5 */
+    double max_ar_deviation;         /* MAX_AR_DEVIATION 0.01 */
+    unsigned int iter_limit;         /* ITER_LIMIT 100000 */
+    double mul;                      /* MUL 0.85 */
+    double adjust_step;              /* DEFAULT_ADJUST_STEP 0.5 */
+    unsigned int iter_readjust;      /* ITER_READJUST 200 */
+    int no_rescaling_limit;          /* NO_RESCALING_LIMIT 15 */
+} orc_calib_cfg;
+
+void orc_calib_defaults(orc_calib_cfg *c);
+
+/* status codes of orc_calibrate (the reference calls exit(1) instead) */
+enum { ORC_CALIB_OK = 0, ORC_CALIB_STEP_TOO_LARGE = 1, ORC_CALIB_ITER_LIMIT = 2 };
+
+/* ---- API ------------------------------------------------------------------ */
+double orc_uniform(orc_rng *r, const orc_state *s, int chain, int slot);
+double orc_gaussian(orc_rng *r, const orc_state *s, int chain, int slot, double sigma);
+
+double orc_loglike(int model, int n_par, const double *params, const double *data,
+                   int n_data, int n_cols, double beta, double sigma, double hmin,
+                   double *prior_out);
+void orc_calc_model(orc_state *s, int chain);
+
+int orc_check_accept(double prob_old, double prob_new, orc_rng *r, const orc_state *s,
+                     int chain, int *drew);
+void orc_markov_chain_step(orc_state *s, orc_rng *r, int chain);
+void orc_markov_chain_step_for(orc_state *s, orc_rng *r, int chain, int p);
+void orc_check_best(orc_state *s, int chain);
+void orc_restart_from_best(orc_state *s, int chain);
+void orc_reset_accept_rejects(orc_state *s, int chain);
+
+double orc_ladder_beta(int kind, unsigned int i, unsigned int n_beta, double beta_0);
+double orc_get_chain_beta(int kind, unsigned int i, unsigned int n_beta, double beta_0);
+double orc_calc_beta_0(const orc_state *s, int chain, const double *stepwidth_factors);
+
+/* returns the swapped pair index a, or -1; if `trace` is non-NULL it receives
+ * {a, r, c} of the attempt */
+int orc_tempering_interaction(orc_state *s, orc_rng *r, double *trace);
+int orc_swap_decision(double a_beta, double b_beta, double a_prob, double b_prob,
+                      double log_u, double *r_out);
+int orc_swap_pair_index(double u, int n_beta);
+
+/* samples: [n_rounds*n_swap][n_chain][n_par+2] = params.., prob, prob-prior ; may be NULL.
+ * n_threads > 1 is only meaningful with ORC_RNG_STREAMS. */
+void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n_swap,
+                     double *samples, int n_threads);
+
+void orc_burn_in(orc_state *s, orc_rng *r, int chain, unsigned int burn_in_iterations);
+int orc_calibrate_orig(orc_state *s, orc_rng *r, int chain, const orc_calib_cfg *cfg,
+                       uint64_t *iters_out);
+int orc_markov_chain_calibrate(orc_state *s, orc_rng *r, int chain, const orc_calib_cfg *cfg,
+                               uint64_t *iters_out);
+int orc_calibrate_first(orc_state *s, orc_rng *r, const orc_calib_cfg *cfg);
+int orc_calibrate_rest(orc_state *s, orc_rng *r, const orc_calib_cfg *cfg, int ladder_kind,
+                       double beta_0, int skip_calibrate_allchains, int n_threads,
+                       double *beta_0_out, double *stepwidth_factors_out);
+
+double orc_mod_double(double x, double y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""Pins the CPU oracle to every known-answer value available for this path.
+
+Sources of the expected values:
+  * GSL's published mt19937 self-test (rng/test.c: seed 4357, 1000th output) and
+    the reference's default seed rule (src/mcmc.c:27-35 -> gsl_rng_env_setup, seed 0 => 4357);
+  * Random123's published Philox4x32-10 known-answer vectors;
+  * the reference manual's eval example (doc/manual.rst:190-213);
+  * the reference's own unit-test fixtures (tests/tests.c:89-160, tests/testinput1,
+    tests/testlc.dat -- copied as data into tests/golden/);
+  * SURVEY.md 8(c) probe values (marked as such: not from real GSL).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def test_mt19937_default_seed_stream():
+    s = orc.mt_stream(0, 1000)           # seed 0 => 4357
+    assert list(s[:3]) == [4293858116, 699692587, 1213834231]
+    assert int(s[999]) == 1186927261     # GSL rng/test.c KAT
+    assert np.array_equal(s, orc.mt_stream(4357, 1000))
+    # numpy's legacy generator uses the same init_genrand(4357)
+    ref = np.random.RandomState(4357).randint(0, 2 ** 32, size=1000, dtype=np.uint64)
+    assert np.array_equal(s.astype(np.uint64), ref)
+
+
+def test_uniform_and_gaussian_kats():
+    lad = orc.Ladder(orc.MODEL_SIMPLESIN, 1, 4, np.zeros((1, 2)))
+    rng = orc.Rng(orc.RNG_GLOBAL_MT, 0)
+    st = lad.c_state()
+    import ctypes as C
+    L = orc.lib()
+    u = [L.orc_uniform(C.byref(rng.c), C.byref(st), 0, 0) for _ in range(3)]
+    assert u == [4293858116 / 2 ** 32, 699692587 / 2 ** 32, 1213834231 / 2 ** 32]
+    assert abs(u[0] - 0.999741748906672) < 1e-15
+    # SURVEY 8(c) probe values (polar method, second variate discarded)
+    rng = orc.Rng(orc.RNG_GLOBAL_MT, 0)
+    g = [L.orc_gaussian(C.byref(rng.c), C.byref(st), 0, 0, 1.0) for _ in range(3)]
+    np.testing.assert_allclose(g, [0.1339186081186759, -0.088100991831438394, 1.6744084062537739],
+                               rtol=1e-14)
+    assert rng.c.draws == 10
+    nxt = math.log(L.orc_uniform(C.byref(rng.c), C.byref(st), 0, 0))
+    assert abs(nxt - (-0.27451079819355362)) < 1e-15
+
+
+def test_philox_random123_kats():
+    assert orc.philox_block([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox_block([0xffffffff] * 4, [0xffffffff] * 2) == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox_block([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                            [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # stream addressing: n-th output = word n%4 of block n/4, subsequence in the upper counter
+    s = orc.philox_stream(0, 0, 8)
+    assert list(s[:4]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert list(s[4:]) == orc.philox_block([1, 0, 0, 0], [0, 0])
+    seed, sub, blk = 0xa4093822 | (0x299f31d0 << 32), 0x13198a2e | (0x03707344 << 32), 0x1243f6a88
+    assert list(orc.philox_stream(seed, sub, 4, start=4 * blk)) == \
+        orc.philox_block([blk & 0xffffffff, blk >> 32, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
+
+
+def test_simplesin_manual_eval_kat():
+    # doc/manual.rst:190-213: data rows and "1 0.2 1 0" -> -1.480898044165363e+01, prior 0
+    data = np.array([[101, 0.67], [102, 1.01], [103, 7.9e-1], [104, 1.34]])
+    prob, prior = orc.loglike(orc.MODEL_SIMPLESIN, [1, 0.2, 1, 0], data, beta=1.0)
+    assert prior == 0.0
+    assert abs(prob - (-1.480898044165363e+01)) < 5e-14
+
+
+def _load_params(path):
+    rows = []
+    for line in open(path):
+        t = line.split()
+        rows.append((float(t[0]), float(t[1]), float(t[2]), t[3], float(t[4])))
+    return rows
+
+
+def test_reference_parser_fixtures(golden_dir):
+    # values asserted by tests/tests.c:95-117
+    p = _load_params(os.path.join(golden_dir, "testinput1"))
+    assert len(p) == 3
+    assert p[0] == (0.7, 0.4, 3.0, "Amplitude", 0.3)
+    assert p[1] == (5.2, 4.0, 24.0, "Frequenz", 0.01)
+    assert p[2] == (5.4, 0.0, 6.1, "Phase", 0.01)
+    d = np.loadtxt(os.path.join(golden_dir, "testlc.dat"))
+    assert d.shape == (1522, 2)
+    assert d[0, 0] == 1.7355217099999998 and d[1, 0] == 1.7356002600000000
+    assert d[1521, 0] == 46.8043750000000003
+    assert d[0, 1] == 0.4731745866773314 and d[1, 1] == -0.9900871130450772
+    assert d[1521, 1] == -0.3527955490681067
+
+
+def test_simplesin_on_reference_lightcurve(golden_dir):
+    # SURVEY 8(c) G1 (probe, libm sin, reproduced there independently in numpy)
+    d = np.loadtxt(os.path.join(golden_dir, "testlc.dat"))
+    for params, want in (((0.7, 5.2, 5.4, 0.0), -3.187159885063915e+03),
+                         ((1.0, 10.0, 0.25, 0.1), -3.271718790429034e+03)):
+        prob, _ = orc.loglike(orc.MODEL_SIMPLESIN, params, d)
+        assert abs(prob - want) < 1e-12 * abs(want)
+        # independent numpy restatement with serial summation order
+        a, f, ph, o = params
+        m = a * np.sin(2.0 * np.pi * (f * d[:, 0] + ph)) + o
+        ss = 0.0
+        for v in (m - d[:, 1]):
+            ss += v * v
+        assert abs(prob - ss / -0.5) < 1e-12 * abs(want)
+
+
+def test_log_and_mod_kats():
+    # tests/tests.c:145-158 (relative 1e-3 there)
+    assert abs(math.log(1e-200) - (-460.5170)) < 1e-3 * 460
+    L = orc.lib()
+    for x, y, want in ((3.14, 3.00, 0.14), (3.14, 1.30, 0.54), (-3.14, 1.30, 0.76), (0, 1.30, 0.0),
+                       (6000.3214, 1.1324, 0.8662), (-6000.3214, 1.1324, 0.2662)):
+        assert abs(L.orc_mod_double(x, y) - want) < 1e-3
+
+
+def test_pulse_models_against_numpy():
+    from apemost_amd import workloads as wl
+    w = wl.pulse(n_data=64, n_chain=2)
+    p = w.start.copy()
+    p[3] = 3.3
+    beta = 0.37
+    prob, prior = orc.loglike(orc.MODEL_PULSE, p, w.data, beta=beta)
+    nu, d = w.data[:, 0], w.data[:, 1]
+    y = sum(p[j + 1] / (1 + (2 * np.pi * (p[j] - nu) * p[0]) ** 2) for j in (2, 4))
+    want_prior = -(np.log(p[3] + 1e-6) + np.log(p[5] + 1e-6)) / 2
+    want = want_prior - beta * (p[1] + np.sum(np.log(y) + d / y))
+    assert abs(prior - want_prior) < 1e-15
+    assert abs(prob - want) < 1e-12 * abs(want)
+
+    w = wl.pulse_vrot(n_data=64, n_chain=2)
+    p = w.start.copy()
+    prob, prior = orc.loglike(orc.MODEL_PULSE_VROT, p, w.data, beta=beta)
+    nu, d = w.data[:, 0], w.data[:, 1]
+    lor = lambda f, h: h / (1 + (2 * np.pi * (f - nu) * p[0]) ** 2)
+    y = lor(p[3], p[4]) + lor(p[5] - p[2], p[6]) + lor(p[5], p[6]) + lor(p[5] + p[2], p[6])
+    want_prior = -(np.log(p[4] + 1e-6) + np.log(p[6] + 1e-6)) / 2
+    want = want_prior - beta * (p[1] + np.sum(np.log(y) + d / y))
+    assert abs(prob - want) < 1e-12 * abs(want)
+
+
+def test_beta_ladder_properties():
+    n = 8
+    b = [orc.get_chain_beta(orc.LADDER_CHEBYSHEV_BETA, i, n, 0.01) for i in range(n)]
+    assert b[0] == 1.0 and abs(b[-1] - 0.01) < 1e-15
+    assert all(b[i] > b[i + 1] for i in range(n - 1))
+    want = [0.01 + 0.99 / 2 * (1 - math.cos((n - 1 - i) * math.pi / (n - 1))) for i in range(n)]
+    np.testing.assert_allclose(b, want, rtol=1e-15)
+    assert orc.get_chain_beta(orc.LADDER_CHEBYSHEV_BETA, 0, 1, 0.3) == 1.0
+    for kind in range(6):
+        assert abs(orc.get_chain_beta(kind, 0, n, 0.05) - 1.0) < 1e-15
+        assert abs(orc.get_chain_beta(kind, n - 1, n, 0.05) - 0.05) < 1e-15
