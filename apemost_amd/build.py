@@ -1,0 +1,40 @@
+"""Builds the in-tree native libraries with hipcc / gcc (no JIT cache: the .so files
+travel to the GPU box with the repo snapshot)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HIP_LIB = os.path.join(HERE, "libapemost_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+             "-Wno-unused-value"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, "apemost_hip.hip"), os.path.join(CSRC, "pt_device.h"),
+            os.path.join(ROOT, "include", "apemost_hip.h")]
+    if force or _stale(HIP_LIB, srcs):
+        cmd = [HIPCC] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", HIP_LIB,
+                                     srcs[0]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_all(force=False, verbose=False):
+    return [build_hip(force, verbose)]
+
+
+if __name__ == "__main__":
+    for p in build_all(force=True, verbose=True):
+        print("built", p)

@@ -1,0 +1,1202 @@
+// apemost_hip.hip -- kernels and C ABI of the gfx950 parallel-tempering engine
+// (declared in include/apemost_hip.h).  Written for MI355X only.
+#include "pt_device.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace apemost;
+
+// ===========================================================================
+// kernels
+// ===========================================================================
+
+// LDS carve (doubles): proposed params [2][64], wave partials [2][16], 8 control words
+constexpr int kFixedLdsDoubles = 2 * kWave + 32 + 8;
+
+struct RoundArgs {
+    DevArrays d;
+    ChainShape sh;
+    int cur;          // which half of the double-buffered fields is current
+    int first;        // first local chain (calc_model on a range)
+    int apply_swap;   // fuse tempering_interaction() for swap-stream position `round`
+    unsigned n_steps; // Metropolis steps in this launch
+    u64 round;
+    double *samples; // [n_steps][n_chains][n_par+2] or nullptr
+};
+
+template <int MODEL, int WAVES, bool LDS_DATA>
+__device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA> &e, const DevArrays &d,
+                                             const ChainShape &sh, double *lds) {
+    constexpr int kThreads = WAVES * kWave;
+    e.tid = threadIdx.x;
+    e.lane = threadIdx.x & (kWave - 1);
+    e.wave = threadIdx.x / kWave;
+    e.n_par = sh.n_par;
+    e.n_data = sh.n_data;
+    e.consts = sh.consts;
+    e.parity = 0;
+    e.s_par = lds;                 // 2*64 doubles
+    e.s_part = lds + 2 * kWave;    // 2*16 doubles
+    double *s_data = lds + kFixedLdsDoubles; // [2*64 | 2*16 | 8 control] then the data vector
+    if (LDS_DATA) {
+        // stage the data vector once per launch: coalesced HBM/L2 reads, SoA in LDS
+        for (int i = e.tid; i < 2 * sh.n_data; i += kThreads)
+            s_data[i] = d.data[i];
+        e.xs = s_data;
+        e.ys = s_data + sh.n_data;
+    } else {
+        e.xs = d.data;
+        e.ys = d.data + sh.n_data;
+    }
+}
+
+// Load the chain into wave 0's registers from the read half of the state.
+template <class E>
+__device__ __forceinline__ void chain_load(E &e, const DevArrays &d, const ChainShape &sh, int c,
+                                           int cur) {
+    const int row = c + 1, n = sh.n_par;
+    e.beta_all = d.beta[row];
+    e.cur = e.best = e.stepw = e.lo = e.hi = 0;
+    e.pacc = e.prej = 0;
+    e.prob = d.prob[cur][row];
+    e.prior = d.prior[cur][row];
+    e.prob_best = d.prob_best[cur][row];
+    e.beta = e.beta_all;
+    e.accept = d.accept[c];
+    e.reject = d.reject[c];
+    if (e.wave == 0) {
+        if (e.lane < n) {
+            const size_t k = (size_t)c * n + e.lane;
+            e.cur = d.params[cur][(size_t)row * n + e.lane];
+            e.best = d.params_best[cur][(size_t)row * n + e.lane];
+            e.stepw = d.step[k];
+            e.lo = d.pmin[k];
+            e.hi = d.pmax[k];
+            e.pacc = d.params_accepts[k];
+            e.prej = d.params_rejects[k];
+        }
+        if (e.lane <= n) {
+            const u64 subseq = (u64)(sh.chain_offset + c) * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)e.lane;
+            e.rng.init(sh.seed, subseq, d.rng_offsets[(size_t)c * (n + 1) + e.lane]);
+        }
+    }
+}
+
+template <class E>
+__device__ __forceinline__ void chain_store(const E &e, const DevArrays &d, const ChainShape &sh,
+                                            int c, int dst, bool store_step) {
+    const int row = c + 1, n = sh.n_par;
+    if (e.wave != 0)
+        return;
+    if (e.lane < n) {
+        const size_t k = (size_t)c * n + e.lane;
+        d.params[dst][(size_t)row * n + e.lane] = e.cur;
+        d.params_best[dst][(size_t)row * n + e.lane] = e.best;
+        d.params_accepts[k] = e.pacc;
+        d.params_rejects[k] = e.prej;
+        if (store_step)
+            d.step[k] = e.stepw;
+    }
+    if (e.lane <= n)
+        d.rng_offsets[(size_t)c * (n + 1) + e.lane] = e.rng.n;
+    if (e.lane == 0) {
+        d.prob[dst][row] = e.prob;
+        d.prior[dst][row] = e.prior;
+        d.prob_best[dst][row] = e.prob_best;
+        d.accept[c] = e.accept;
+        d.reject[c] = e.reject;
+    }
+}
+
+// tempering_interaction() fused into the start of a round
+// (src/parallel_tempering_interaction.c:25-42, 87-123, 125-141).  Every
+// workgroup derives the same pair and the same uniforms from the replicated swap
+// stream; the two workgroups of the pair evaluate the same expression on the same
+// (read-only) values, so they agree without talking to each other.
+template <class E>
+__device__ __forceinline__ void swap_in(E &e, const DevArrays &d, const ChainShape &sh, int c, int cur,
+                                        u64 round) {
+    if (sh.n_global <= 1 || e.wave != 0)
+        return;
+    Stream sw;
+    sw.init(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, 4 * round);
+    const double u = sw.uniform();
+    const double lc = sw.alog_uniform();
+    const int nb = (int)sh.n_global;
+    const long long a = (int)(nb * 1000 * u) % (nb - 1);
+    const long long g = sh.chain_offset + c;
+    if (g != a && g != a + 1)
+        return;
+    const int n = sh.n_par;
+    const int row = c + 1;
+    const int row_a = (g == a) ? row : row - 1, row_b = row_a + 1;
+    const int partner = (g == a) ? row_b : row_a;
+    const double a_prob = d.prob[cur][row_a], b_prob = d.prob[cur][row_b];
+    const double a_beta = d.beta[row_a], b_beta = d.beta[row_b];
+    const double r = a_beta * b_prob / b_beta + b_beta * a_prob / a_beta - (a_prob + b_prob);
+    if (!(r > lc))
+        return;
+    // parallel_tempering_do_swap: params exchanged, prob is not (quirk Q1)
+    if (e.lane < n)
+        e.cur = d.params[cur][(size_t)partner * n + e.lane];
+    const double a_best = d.prob_best[cur][row_a], b_best = d.prob_best[cur][row_b];
+    const bool a_wins = a_best > b_best;
+    if ((g == a) != a_wins) { // this chain receives the other one's best (quirk Q3)
+        e.prob_best = a_wins ? a_best : b_best;
+        if (e.lane < n)
+            e.best = d.params_best[cur][(size_t)partner * n + e.lane];
+    }
+    if (g == a && e.lane == 0)
+        d.swapcount[c] += 1; // inc_swapcount(chains[candidate])
+}
+
+template <int MODEL, int WAVES, bool LDS_DATA>
+__global__ __launch_bounds__(WAVES *kWave) void pt_round_kernel(const RoundArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    Engine<MODEL, WAVES, LDS_DATA> e;
+    const int c = blockIdx.x;
+    engine_setup(e, a.d, a.sh, lds);
+    chain_load(e, a.d, a.sh, c, a.cur);
+    if (a.apply_swap)
+        swap_in(e, a.d, a.sh, c, a.cur, a.round);
+    __syncthreads();
+
+    const int n = a.sh.n_par;
+    for (unsigned s = 0; s < a.n_steps; s++) {
+        e.step(-1);
+        if (e.wave == 0) {
+            e.check_best();
+            if (a.samples) {
+                // the row the reference prints per step: params ("%.15e"), prob, prob-prior
+                double *row = a.samples + ((size_t)s * a.sh.n_chains + c) * (n + 2);
+                if (e.lane < n)
+                    row[e.lane] = e.cur;
+                else if (e.lane == n)
+                    row[n] = e.prob;
+                else if (e.lane == n + 1)
+                    row[n + 1] = e.prob - e.prior;
+            }
+        }
+    }
+    if (e.wave == 0 && e.lane == 0)
+        a.d.n_iter[c] += a.n_steps; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
+    chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
+}
+
+// calc_model() for every resident chain, in place
+template <int MODEL, int WAVES, bool LDS_DATA>
+__global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const RoundArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    Engine<MODEL, WAVES, LDS_DATA> e;
+    const int c = a.first + blockIdx.x;
+    engine_setup(e, a.d, a.sh, lds);
+    chain_load(e, a.d, a.sh, c, a.cur);
+    __syncthreads();
+    e.calc_model_current();
+    if (e.wave == 0 && e.lane == 0) {
+        a.d.prob[a.cur][c + 1] = e.prob;
+        a.d.prior[a.cur][c + 1] = e.prior;
+    }
+}
+
+// calc_model() at arbitrary points: params [n][n_par], beta [n] -> prob[n], prior[n]
+struct EvalArgs {
+    ChainShape sh;
+    const double *data;
+    const double *params;
+    const double *beta;
+    double *prob;
+    double *prior;
+};
+
+template <int MODEL, int WAVES, bool LDS_DATA>
+__global__ __launch_bounds__(WAVES *kWave) void pt_loglike_kernel(const EvalArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    Engine<MODEL, WAVES, LDS_DATA> e;
+    DevArrays d;
+    d.data = a.data;
+    const int c = blockIdx.x;
+    engine_setup(e, d, a.sh, lds);
+    e.beta_all = e.beta = a.beta[c];
+    e.prior = 0;
+    e.cur = (e.wave == 0 && e.lane < a.sh.n_par) ? a.params[(size_t)c * a.sh.n_par + e.lane] : 0.0;
+    __syncthreads();
+    e.calc_model_current();
+    if (e.wave == 0 && e.lane == 0) {
+        a.prob[c] = e.prob;
+        a.prior[c] = e.prior;
+    }
+}
+
+// ---- calibration: burn_in + markov_chain_calibrate_orig as a per-chain state machine ----
+struct CalibArgs {
+    DevArrays d;
+    ChainShape sh;
+    int cur;
+    int first;        // first local chain
+    int burn_in_only; // -DSKIP_CALIBRATE_ALLCHAINS
+    apemost_hip_calib_config cfg;
+    int *status;      // [count]
+    u64 *iters;       // [count]
+};
+
+template <int MODEL, int WAVES, bool LDS_DATA>
+__global__ __launch_bounds__(WAVES *kWave) void pt_calibrate_kernel(const CalibArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    // control word decided by wave 0, read by every wave (kept inside the dynamic
+    // region so the carve base stays 16-byte aligned)
+    volatile int &s_ctl = *(volatile int *)(lds + 2 * kWave + 32);
+    Engine<MODEL, WAVES, LDS_DATA> e;
+    const int c = a.first + blockIdx.x;
+    const int n = a.sh.n_par;
+    engine_setup(e, a.d, a.sh, lds);
+    chain_load(e, a.d, a.sh, c, a.cur);
+    __syncthreads();
+    const bool w0 = (e.wave == 0);
+    const apemost_hip_calib_config &cfg = a.cfg;
+
+    // ---- burn_in: src/markov_chain.c:34-79 ----
+    const double original_step = e.stepw;
+    e.stepw = (e.hi - e.lo) * 0.1;
+    unsigned long iter = 0;
+    for (; iter < cfg.burn_in_iterations / 2;) {
+        for (int sub = 0; sub < 200; sub++)
+            e.step(-1);
+        iter += 200;
+        if (w0)
+            e.check_best();
+    }
+    if (w0)
+        e.restart_from_best();
+    e.stepw *= 0.5;
+    for (; iter < cfg.burn_in_iterations;) {
+        for (int sub = 0; sub < 200; sub++)
+            e.step(-1);
+        iter += 200;
+        if (w0)
+            e.check_best();
+    }
+    e.stepw = original_step;
+
+    int status = 0;
+    unsigned long sweeps = 0;
+    if (!a.burn_in_only) {
+        // ---- markov_chain_calibrate_orig: src/markov_chain_calibrate.c:1039-1180 ----
+        double rat_limit = pow(cfg.rat_limit, 1.0 / n);
+        int nchecks_without_rescaling = 0;
+        e.stepw *= cfg.adjust_step;
+        e.reset_accept_rejects();
+        while (true) {
+            for (int p = 0; p < n; p++) {
+                e.step(p);
+                if (w0)
+                    e.check_best();
+            }
+            sweeps++;
+            if (sweeps % cfg.iter_readjust != 0)
+                continue;
+            // per-parameter rescaling; lane p decides for parameter p, the wave
+            // combines the decisions in parameter order like the reference's loop
+            int rescaled = 0, fail = 0;
+            if (w0) {
+                int up = 0, clamped = 0, down = 0, too_large = 0;
+                if (e.lane < n) {
+                    const double ar = (double)e.pacc / ((double)e.prej + (double)e.pacc);
+                    if (ar > rat_limit + 0.05) {
+                        up = 1;
+                        e.stepw = e.stepw / cfg.mul;
+                        if (e.stepw / (e.hi - e.lo) > 1) {
+                            e.stepw = 1 * (e.hi - e.lo);
+                            clamped = 1;
+                        }
+                        if (e.stepw / (e.hi - e.lo) > 10000)
+                            too_large = 1;
+                    }
+                    if (ar < rat_limit - 0.05) {
+                        down = 1;
+                        e.stepw = e.stepw * cfg.mul;
+                    }
+                }
+                for (int p = 0; p < n; p++) {
+                    const int up_p = __shfl(up, p, kWave), cl_p = __shfl(clamped, p, kWave);
+                    const int dn_p = __shfl(down, p, kWave), tl_p = __shfl(too_large, p, kWave);
+                    if (up_p) {
+                        if (rescaled == 0)
+                            rescaled = -1;
+                        if (cl_p && rescaled == -1)
+                            rescaled = 0;
+                        if (tl_p && !fail)
+                            fail = 1;
+                        if (rescaled == -1)
+                            rescaled = 1;
+                    }
+                    if (dn_p)
+                        rescaled = 1;
+                }
+                if (e.tid == 0)
+                    s_ctl = fail;
+            }
+            __syncthreads();
+            fail = s_ctl;
+            __syncthreads();
+            if (fail) {
+                status = 1;
+                break;
+            }
+            if (w0) {
+                if (rescaled == 0)
+                    nchecks_without_rescaling++;
+                e.restart_from_best();
+                e.reset_accept_rejects();
+            }
+            for (unsigned sub = 0; sub < cfg.iter_readjust; sub++) {
+                e.step(-1);
+                if (w0)
+                    e.check_best();
+            }
+            int ctl = 0; // 0 continue, 1 converged, 2 iteration limit
+            if (w0) {
+                const double delta =
+                    (double)e.accept / (double)(e.accept + e.reject) - cfg.target_global;
+                int reached_perfection;
+                if ((delta < 0 ? -delta : delta) < cfg.max_ar_deviation) {
+                    reached_perfection = 1;
+                } else {
+                    reached_perfection = 0;
+                    if (delta < 0)
+                        rat_limit /= 0.99;
+                    else
+                        rat_limit *= 0.99;
+                }
+                if (nchecks_without_rescaling >= cfg.no_rescaling_limit && reached_perfection == 1 &&
+                    rescaled == 0)
+                    ctl = 1;
+                else if (sweeps > cfg.iter_limit)
+                    ctl = 2;
+                if (e.tid == 0)
+                    s_ctl = ctl;
+            }
+            __syncthreads();
+            ctl = s_ctl;
+            __syncthreads();
+            if (ctl == 1)
+                break;
+            if (ctl == 2) {
+                status = 2;
+                break;
+            }
+        }
+        if (status == 0 && w0)
+            e.reset_accept_rejects();
+    }
+    if (e.tid == 0) {
+        a.status[blockIdx.x] = status;
+        a.iters[blockIdx.x] = sweeps;
+    }
+    // calibration leaves the chain in place: same half of the double buffer
+    chain_store(e, a.d, a.sh, c, a.cur, true);
+}
+
+// ---- test hooks ----
+__global__ void rng_raw_kernel(u64 seed, u64 subseq, u64 offset, int n, unsigned int *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    Stream s;
+    s.init(seed, subseq, offset);
+    for (int i = 0; i < n; i++)
+        out[i] = s.next();
+}
+
+__global__ void rng_gaussian_kernel(u64 seed, u64 subseq, u64 offset, double sigma, int n, double *out,
+                                    u64 *consumed) {
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    Stream s;
+    s.init(seed, subseq, offset);
+    for (int i = 0; i < n; i++)
+        out[i] = s.gaussian(sigma);
+    *consumed = s.n - offset;
+}
+
+// edge records for sharded ladders: beta, prob, prob_best, params[n], params_best[n]
+__global__ void edge_export_kernel(DevArrays d, int n_par, int cur, int row, double *buf) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        buf[0] = d.beta[row];
+        buf[1] = d.prob[cur][row];
+        buf[2] = d.prob_best[cur][row];
+    }
+    if (t < n_par) {
+        buf[3 + t] = d.params[cur][(size_t)row * n_par + t];
+        buf[3 + n_par + t] = d.params_best[cur][(size_t)row * n_par + t];
+    }
+}
+
+__global__ void edge_import_kernel(DevArrays d, int n_par, int cur, int row, const double *buf) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        d.beta[row] = buf[0];
+        d.prob[cur][row] = buf[1];
+        d.prob_best[cur][row] = buf[2];
+    }
+    if (t < n_par) {
+        d.params[cur][(size_t)row * n_par + t] = buf[3 + t];
+        d.params_best[cur][(size_t)row * n_par + t] = buf[3 + n_par + t];
+    }
+}
+
+// ===========================================================================
+// host side of the C ABI
+// ===========================================================================
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t err__ = (expr);                                                               \
+        if (err__ != hipSuccess)                                                                 \
+            return fail(APEMOST_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr,                 \
+                        hipGetErrorString(err__), __FILE__, __LINE__);                           \
+    } while (0)
+
+struct apemost_hip_sampler {
+    apemost_hip_config cfg;
+    DevArrays d;
+    ChainShape sh;
+    int waves;
+    bool lds_data;
+    size_t lds_bytes;
+    int cur;
+    u64 round;
+    int swap_pending;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    u64 launches, launches_at_begin;
+    std::vector<void *> allocations;
+    int *d_status;
+    u64 *d_iters;
+    int calib_capacity;
+};
+
+extern "C" const char *apemost_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int apemost_hip_abi_version(void) { return APEMOST_HIP_ABI_VERSION; }
+
+extern "C" int apemost_hip_device_count(int *count) {
+    if (!count)
+        return fail(APEMOST_HIP_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0) {
+        *count = 0;
+        return fail(APEMOST_HIP_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(err));
+    }
+    *count = n;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_device_info(int device, char *name, size_t name_len, int *compute_units,
+                                       uint64_t *hbm_bytes) {
+    int n = 0;
+    int rc = apemost_hip_device_count(&n);
+    if (rc != APEMOST_HIP_OK)
+        return rc;
+    if (device < 0 || device >= n)
+        return fail(APEMOST_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units)
+        *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = prop.totalGlobalMem;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(APEMOST_HIP_ERR_NO_DEVICE, "device %d is %s; this engine is built for gfx950 only",
+                    device, prop.gcnArchName);
+    return APEMOST_HIP_OK;
+}
+
+static int enable_big_lds(apemost_hip_sampler *s);
+
+template <class T>
+static int dev_alloc(apemost_hip_sampler *s, T **p, size_t count) {
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    HIP_TRY(hipMemsetAsync(q, 0, (count ? count : 1) * sizeof(T), s->stream));
+    s->allocations.push_back(q);
+    *p = (T *)q;
+    return APEMOST_HIP_OK;
+}
+
+static int choose_waves(const apemost_hip_config &c) {
+    if (c.waves_per_chain > 0)
+        return c.waves_per_chain;
+    // enough wavefronts to spread the chip's 1024 SIMDs over the resident chains,
+    // but never fewer than 4 data points per lane and never more than 16 waves
+    int by_chip = 1;
+    while (by_chip < 16 && (long long)c.n_chains * by_chip * 2 <= 2048)
+        by_chip *= 2;
+    int by_data = 1;
+    while (by_data < 16 && c.n_data >= by_data * 2 * kWave * 4)
+        by_data *= 2;
+    return by_chip < by_data ? by_chip : by_data;
+}
+
+extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sampler **out) {
+    if (!cfg || !out)
+        return fail(APEMOST_HIP_ERR_INVALID, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->abi_version != APEMOST_HIP_ABI_VERSION)
+        return fail(APEMOST_HIP_ERR_INVALID, "ABI version %d, library has %d", cfg->abi_version,
+                    APEMOST_HIP_ABI_VERSION);
+    if (cfg->n_par < 1 || cfg->n_par > APEMOST_HIP_MAX_PAR)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_par %d outside [1,%d]", cfg->n_par, APEMOST_HIP_MAX_PAR);
+    if (cfg->n_chains < 1 || cfg->n_data < 1 || cfg->n_cols < 2)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_chains %d, n_data %d, n_cols %d invalid", cfg->n_chains,
+                    cfg->n_data, cfg->n_cols);
+    if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->n_chains > cfg->n_chains_global)
+        return fail(APEMOST_HIP_ERR_INVALID, "shard [%lld,%lld) outside ladder of %lld chains",
+                    (long long)cfg->chain_offset, (long long)(cfg->chain_offset + cfg->n_chains),
+                    (long long)cfg->n_chains_global);
+    if (cfg->n_chains_global > 2000000)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_beta*1000 must fit an int (interaction.c:92)");
+    switch (cfg->model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        if (cfg->n_par != 4)
+            return fail(APEMOST_HIP_ERR_INVALID, "simplesin needs n_par = 4");
+        break;
+    case APEMOST_MODEL_SINE3:
+        if (cfg->n_par != 10)
+            return fail(APEMOST_HIP_ERR_INVALID, "sine3 needs n_par = 10");
+        break;
+    case APEMOST_MODEL_PULSE:
+        if (cfg->n_par < 4 || (cfg->n_par - 2) % 2 != 0)
+            return fail(APEMOST_HIP_ERR_INVALID, "pulse needs n_par = 2 + 2*modes");
+        break;
+    case APEMOST_MODEL_PULSE_VROT:
+        if (cfg->n_par != 7)
+            return fail(APEMOST_HIP_ERR_INVALID, "pulse_vrot needs n_par = 7");
+        break;
+    default:
+        return fail(APEMOST_HIP_ERR_UNSUPPORTED, "unknown device model %d", cfg->model);
+    }
+    int rc = apemost_hip_device_info(cfg->device, nullptr, 0, nullptr, nullptr);
+    if (rc != APEMOST_HIP_OK)
+        return rc;
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    apemost_hip_sampler *s = new apemost_hip_sampler();
+    s->cfg = *cfg;
+    s->cur = 0;
+    s->round = 0;
+    s->swap_pending = 0;
+    s->launches = 0;
+    s->launches_at_begin = 0;
+    s->d_status = nullptr;
+    s->d_iters = nullptr;
+    s->calib_capacity = 0;
+    s->waves = choose_waves(*cfg);
+    if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 8 && s->waves != 16) {
+        delete s;
+        return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 8 or 16");
+    }
+    const size_t fixed_lds = kFixedLdsDoubles * sizeof(double);
+    const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
+    s->lds_data = fixed_lds + data_lds <= 160 * 1024 - 1024;
+    s->lds_bytes = fixed_lds + (s->lds_data ? data_lds : 0);
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+
+    const size_t n = cfg->n_chains, np = cfg->n_par, rows = n + 2;
+    DevArrays &d = s->d;
+    for (int h = 0; h < 2; h++) {
+        if ((rc = dev_alloc(s, &d.params[h], rows * np)) || (rc = dev_alloc(s, &d.params_best[h], rows * np)) ||
+            (rc = dev_alloc(s, &d.prob[h], rows)) || (rc = dev_alloc(s, &d.prob_best[h], rows)) ||
+            (rc = dev_alloc(s, &d.prior[h], rows)))
+            return rc;
+    }
+    double *data = nullptr;
+    if ((rc = dev_alloc(s, &d.beta, rows)) || (rc = dev_alloc(s, &d.step, n * np)) ||
+        (rc = dev_alloc(s, &d.pmin, n * np)) || (rc = dev_alloc(s, &d.pmax, n * np)) ||
+        (rc = dev_alloc(s, &d.params_accepts, n * np)) || (rc = dev_alloc(s, &d.params_rejects, n * np)) ||
+        (rc = dev_alloc(s, &d.accept, n)) || (rc = dev_alloc(s, &d.reject, n)) ||
+        (rc = dev_alloc(s, &d.n_iter, n)) || (rc = dev_alloc(s, &d.swapcount, n)) ||
+        (rc = dev_alloc(s, &d.rng_offsets, n * (np + 1))) ||
+        (rc = dev_alloc(s, &data, (size_t)cfg->n_cols * cfg->n_data)))
+        return rc;
+    d.data = data;
+
+    s->sh.n_par = cfg->n_par;
+    s->sh.n_data = cfg->n_data;
+    s->sh.n_chains = cfg->n_chains;
+    s->sh.chain_offset = cfg->chain_offset;
+    s->sh.n_global = cfg->n_chains_global;
+    s->sh.seed = cfg->seed;
+    s->sh.consts.sigma = cfg->sigma;
+    s->sh.consts.hmin = cfg->hmin;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if ((rc = enable_big_lds(s)))
+        return rc;
+    *out = s;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_destroy(apemost_hip_sampler *s) {
+    if (!s)
+        return APEMOST_HIP_OK;
+    hipSetDevice(s->cfg.device);
+    hipStreamSynchronize(s->stream);
+    for (void *p : s->allocations)
+        hipFree(p);
+    if (s->d_status)
+        hipFree(s->d_status);
+    if (s->d_iters)
+        hipFree(s->d_iters);
+    hipEventDestroy(s->ev0);
+    hipEventDestroy(s->ev1);
+    hipStreamDestroy(s->stream);
+    delete s;
+    return APEMOST_HIP_OK;
+}
+
+#define CHECK_S(s)                                                                               \
+    do {                                                                                         \
+        if (!(s))                                                                                \
+            return fail(APEMOST_HIP_ERR_INVALID, "sampler is NULL");                             \
+        HIP_TRY(hipSetDevice((s)->cfg.device));                                                  \
+    } while (0)
+
+extern "C" int apemost_hip_synchronize(apemost_hip_sampler *s) {
+    CHECK_S(s);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_stream(apemost_hip_sampler *s, void **stream) {
+    CHECK_S(s);
+    if (!stream)
+        return fail(APEMOST_HIP_ERR_INVALID, "stream is NULL");
+    *stream = (void *)s->stream;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, int *data_in_lds) {
+    CHECK_S(s);
+    if (waves)
+        *waves = s->waves;
+    if (data_in_lds)
+        *data_in_lds = s->lds_data ? 1 : 0;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_set_data(apemost_hip_sampler *s, const double *data_rowmajor) {
+    CHECK_S(s);
+    if (!data_rowmajor)
+        return fail(APEMOST_HIP_ERR_INVALID, "data is NULL");
+    const int n = s->cfg.n_data, nc = s->cfg.n_cols;
+    std::vector<double> col((size_t)n * nc);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < nc; j++)
+            col[(size_t)j * n + i] = data_rowmajor[(size_t)i * nc + j];
+    HIP_TRY(hipMemcpyAsync((void *)s->d.data, col.data(), col.size() * sizeof(double),
+                           hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return APEMOST_HIP_OK;
+}
+
+// copy one [n_chains][width] field between host and the interior rows of a device array
+template <class T>
+static int xfer(apemost_hip_sampler *s, T *dev, T *host, size_t width, bool rows_layout, bool to_device) {
+    if (!host)
+        return APEMOST_HIP_OK;
+    T *p = dev + (rows_layout ? width : 0);
+    const size_t bytes = (size_t)s->cfg.n_chains * width * sizeof(T);
+    if (to_device)
+        HIP_TRY(hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, s->stream));
+    else
+        HIP_TRY(hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, s->stream));
+    return APEMOST_HIP_OK;
+}
+
+static int xfer_state(apemost_hip_sampler *s, const apemost_hip_state_view *v, bool up) {
+    CHECK_S(s);
+    if (!v)
+        return fail(APEMOST_HIP_ERR_INVALID, "state view is NULL");
+    const size_t np = s->cfg.n_par;
+    const int h = s->cur;
+    DevArrays &d = s->d;
+    int rc;
+    if ((rc = xfer(s, d.params[h], v->params, np, true, up)) ||
+        (rc = xfer(s, d.params_best[h], v->params_best, np, true, up)) ||
+        (rc = xfer(s, d.prob[h], v->prob, 1, true, up)) ||
+        (rc = xfer(s, d.prob_best[h], v->prob_best, 1, true, up)) ||
+        (rc = xfer(s, d.prior[h], v->prior, 1, true, up)) || (rc = xfer(s, d.beta, v->beta, 1, true, up)) ||
+        (rc = xfer(s, d.step, v->step, np, false, up)) || (rc = xfer(s, d.pmin, v->pmin, np, false, up)) ||
+        (rc = xfer(s, d.pmax, v->pmax, np, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.params_accepts, v->params_accepts, np, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.params_rejects, v->params_rejects, np, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.accept, v->accept, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.reject, v->reject, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.n_iter, v->n_iter, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.swapcount, v->swapcount, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.rng_offsets, v->rng_offsets, np + 1, false, up)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_set_state(apemost_hip_sampler *s, const apemost_hip_state_view *v) {
+    return xfer_state(s, v, true);
+}
+extern "C" int apemost_hip_get_state(apemost_hip_sampler *s, const apemost_hip_state_view *v) {
+    return xfer_state(s, v, false);
+}
+
+extern "C" int apemost_hip_set_round(apemost_hip_sampler *s, uint64_t round, int swap_pending) {
+    CHECK_S(s);
+    s->round = round;
+    s->swap_pending = swap_pending ? 1 : 0;
+    return APEMOST_HIP_OK;
+}
+extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, int *swap_pending) {
+    CHECK_S(s);
+    if (round)
+        *round = s->round;
+    if (swap_pending)
+        *swap_pending = s->swap_pending;
+    return APEMOST_HIP_OK;
+}
+
+// ---- launch dispatch over (model, waves, lds) ----
+enum KernelKind { K_ROUND, K_CALC, K_EVAL, K_CALIB };
+
+template <int MODEL, int WAVES, bool LDS>
+static hipError_t launch_one(KernelKind kind, int grid, size_t lds, hipStream_t st, const void *args) {
+    const dim3 g(grid), b(WAVES * kWave);
+    switch (kind) {
+    case K_ROUND:
+        hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS>), g, b, lds, st, *(const RoundArgs *)args);
+        break;
+    case K_CALC:
+        hipLaunchKernelGGL((pt_calc_model_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
+                           *(const RoundArgs *)args);
+        break;
+    case K_EVAL:
+        hipLaunchKernelGGL((pt_loglike_kernel<MODEL, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
+        break;
+    case K_CALIB:
+        hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
+                           *(const CalibArgs *)args);
+        break;
+    }
+    return hipGetLastError();
+}
+
+template <int MODEL, bool LDS>
+static hipError_t launch_w(int waves, KernelKind kind, int grid, size_t lds, hipStream_t st,
+                           const void *args) {
+    switch (waves) {
+    case 1:
+        return launch_one<MODEL, 1, LDS>(kind, grid, lds, st, args);
+    case 2:
+        return launch_one<MODEL, 2, LDS>(kind, grid, lds, st, args);
+    case 4:
+        return launch_one<MODEL, 4, LDS>(kind, grid, lds, st, args);
+    case 8:
+        return launch_one<MODEL, 8, LDS>(kind, grid, lds, st, args);
+    default:
+        return launch_one<MODEL, 16, LDS>(kind, grid, lds, st, args);
+    }
+}
+
+template <int MODEL>
+static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, int grid, size_t lds, hipStream_t st,
+                           const void *args) {
+    return lds_data ? launch_w<MODEL, true>(waves, kind, grid, lds, st, args)
+                    : launch_w<MODEL, false>(waves, kind, grid, lds, st, args);
+}
+
+static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args) {
+    hipError_t err;
+    switch (s->cfg.model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        err = launch_m<APEMOST_MODEL_SIMPLESIN>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        break;
+    case APEMOST_MODEL_PULSE:
+        err = launch_m<APEMOST_MODEL_PULSE>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        break;
+    case APEMOST_MODEL_PULSE_VROT:
+        err = launch_m<APEMOST_MODEL_PULSE_VROT>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        break;
+    default:
+        err = launch_m<APEMOST_MODEL_SINE3>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        break;
+    }
+    if (err != hipSuccess)
+        return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));
+    return APEMOST_HIP_OK;
+}
+
+static int enable_big_lds(apemost_hip_sampler *s);
+
+extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int32_t count) {
+    CHECK_S(s);
+    if (count < 0)
+        count = s->cfg.n_chains - first;
+    if (first < 0 || count < 1 || first + count > s->cfg.n_chains)
+        return fail(APEMOST_HIP_ERR_INVALID, "calc_model: chains [%d,%d) outside [0,%d)", first,
+                    first + count, s->cfg.n_chains);
+    RoundArgs a;
+    a.d = s->d;
+    a.sh = s->sh;
+    a.cur = s->cur;
+    a.first = first;
+    a.apply_swap = 0;
+    a.n_steps = 0;
+    a.round = 0;
+    a.samples = nullptr;
+    return launch(s, K_CALC, count, &a);
+}
+
+extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params,
+                                   const double *beta, double *prob, double *prior) {
+    CHECK_S(s);
+    if (n < 1 || !params || !beta || !prob)
+        return fail(APEMOST_HIP_ERR_INVALID, "loglike: bad arguments");
+    const size_t np = s->cfg.n_par;
+    double *d_params, *d_beta, *d_prob, *d_prior;
+    HIP_TRY(hipMalloc((void **)&d_params, n * np * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&d_beta, n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&d_prob, n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&d_prior, n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(d_params, params, n * np * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(d_beta, beta, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    EvalArgs a;
+    a.sh = s->sh;
+    a.data = s->d.data;
+    a.params = d_params;
+    a.beta = d_beta;
+    a.prob = d_prob;
+    a.prior = d_prior;
+    int rc = launch(s, K_EVAL, n, &a);
+    if (!rc) {
+        HIP_TRY(hipMemcpyAsync(prob, d_prob, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        if (prior)
+            HIP_TRY(hipMemcpyAsync(prior, d_prior, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    hipFree(d_params);
+    hipFree(d_beta);
+    hipFree(d_prob);
+    hipFree(d_prior);
+    return rc;
+}
+
+// kernels that stage > 64 KiB of data in LDS must opt in once per function
+template <int MODEL, int WAVES>
+static hipError_t set_lds_attr(size_t bytes) {
+    hipError_t e;
+    e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return e;
+    e = hipFuncSetAttribute((const void *)pt_calc_model_kernel<MODEL, WAVES, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return e;
+    e = hipFuncSetAttribute((const void *)pt_loglike_kernel<MODEL, WAVES, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return e;
+    return hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int MODEL>
+static hipError_t set_lds_attr_w(int waves, size_t bytes) {
+    switch (waves) {
+    case 1:
+        return set_lds_attr<MODEL, 1>(bytes);
+    case 2:
+        return set_lds_attr<MODEL, 2>(bytes);
+    case 4:
+        return set_lds_attr<MODEL, 4>(bytes);
+    case 8:
+        return set_lds_attr<MODEL, 8>(bytes);
+    default:
+        return set_lds_attr<MODEL, 16>(bytes);
+    }
+}
+
+static int enable_big_lds(apemost_hip_sampler *s) {
+    if (!s->lds_data || s->lds_bytes <= 64 * 1024)
+        return APEMOST_HIP_OK;
+    hipError_t e;
+    switch (s->cfg.model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        e = set_lds_attr_w<APEMOST_MODEL_SIMPLESIN>(s->waves, s->lds_bytes);
+        break;
+    case APEMOST_MODEL_PULSE:
+        e = set_lds_attr_w<APEMOST_MODEL_PULSE>(s->waves, s->lds_bytes);
+        break;
+    case APEMOST_MODEL_PULSE_VROT:
+        e = set_lds_attr_w<APEMOST_MODEL_PULSE_VROT>(s->waves, s->lds_bytes);
+        break;
+    default:
+        e = set_lds_attr_w<APEMOST_MODEL_SINE3>(s->waves, s->lds_bytes);
+        break;
+    }
+    if (e != hipSuccess)
+        return fail(APEMOST_HIP_ERR_RUNTIME, "hipFuncSetAttribute(LDS %zu B): %s", s->lds_bytes,
+                    hipGetErrorString(e));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap,
+                                        double *d_samples) {
+    CHECK_S(s);
+    int rc;
+    RoundArgs a;
+    a.d = s->d;
+    a.sh = s->sh;
+    a.cur = s->cur;
+    a.first = 0;
+    a.apply_swap = apply_swap ? 1 : 0;
+    a.n_steps = n_steps;
+    a.round = s->round;
+    a.samples = d_samples;
+    rc = launch(s, K_ROUND, s->cfg.n_chains, &a);
+    if (rc)
+        return rc;
+    s->cur ^= 1;
+    s->launches++;
+    if (apply_swap) {
+        s->round++;
+        s->swap_pending = 0;
+    }
+    if (n_steps > 0)
+        s->swap_pending = 1;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32_t n_swap,
+                               double *d_samples) {
+    CHECK_S(s);
+    if (s->cfg.n_chains != s->cfg.n_chains_global)
+        return fail(APEMOST_HIP_ERR_INVALID,
+                    "apemost_hip_run needs the whole ladder on one device; sharded ladders drive "
+                    "apemost_hip_launch_round + apemost_hip_edge_*");
+    const size_t row = (size_t)s->cfg.n_chains * (s->cfg.n_par + 2);
+    for (uint64_t r = 0; r < n_rounds; r++) {
+        int rc = apemost_hip_launch_round(s, n_swap, s->swap_pending,
+                                          d_samples ? d_samples + r * n_swap * row : nullptr);
+        if (rc)
+            return rc;
+    }
+    if (s->swap_pending)
+        return apemost_hip_launch_round(s, 0, 1, nullptr);
+    return APEMOST_HIP_OK;
+}
+
+// host Philox4x32-10, bit-identical to the device's rocRAND stream; only used to
+// tell sharded hosts which pair the next swap touches
+static void philox_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, k[2] = {key[0], key[1]};
+    for (int i = 0; i < 10; i++) {
+        const uint64_t m0 = (uint64_t)ROCRAND_PHILOX_M4x32_0 * c[0];
+        const uint64_t m1 = (uint64_t)ROCRAND_PHILOX_M4x32_1 * c[2];
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)m1;
+        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)m0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+        k[0] += ROCRAND_PHILOX_W32_0;
+        k[1] += ROCRAND_PHILOX_W32_1;
+    }
+    memcpy(out, c, sizeof c);
+}
+
+extern "C" int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t n_chains_global) {
+    if (n_chains_global <= 1)
+        return -1;
+    const uint64_t sub = APEMOST_HIP_SWAP_SUBSEQUENCE;
+    uint32_t ctr[4] = {(uint32_t)round, (uint32_t)(round >> 32), (uint32_t)sub, (uint32_t)(sub >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, out[4];
+    philox_host(ctr, key, out);
+    const double u = out[0] * (1.0 / 4294967296.0);
+    const int nb = (int)n_chains_global;
+    return (int)(nb * 1000 * u) % (nb - 1);
+}
+
+extern "C" int32_t apemost_hip_edge_doubles(int32_t n_par) { return 3 + 2 * n_par; }
+
+extern "C" int apemost_hip_edge_export(apemost_hip_sampler *s, int side, double *d_buf) {
+    CHECK_S(s);
+    if (!d_buf || (side != 0 && side != 1))
+        return fail(APEMOST_HIP_ERR_INVALID, "edge_export: bad arguments");
+    const int row = side == 0 ? 1 : s->cfg.n_chains;
+    hipLaunchKernelGGL(edge_export_kernel, dim3(1), dim3(kWave), 0, s->stream, s->d, s->cfg.n_par, s->cur, row,
+                       d_buf);
+    HIP_TRY(hipGetLastError());
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_edge_import(apemost_hip_sampler *s, int side, const double *d_buf) {
+    CHECK_S(s);
+    if (!d_buf || (side != 0 && side != 1))
+        return fail(APEMOST_HIP_ERR_INVALID, "edge_import: bad arguments");
+    const int row = side == 0 ? 0 : s->cfg.n_chains + 1;
+    hipLaunchKernelGGL(edge_import_kernel, dim3(1), dim3(kWave), 0, s->stream, s->d, s->cfg.n_par, s->cur, row,
+                       d_buf);
+    HIP_TRY(hipGetLastError());
+    return APEMOST_HIP_OK;
+}
+
+extern "C" void apemost_hip_calib_defaults(apemost_hip_calib_config *c) {
+    if (!c)
+        return;
+    c->burn_in_iterations = 10000;
+    c->iter_limit = 100000;
+    c->iter_readjust = 200;
+    c->no_rescaling_limit = 15;
+    c->rat_limit = 0.5;
+    c->target_global = 0.5;
+    c->max_ar_deviation = 0.01;
+    c->mul = 0.85;
+    c->adjust_step = 0.5;
+}
+
+extern "C" int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t count,
+                                            const apemost_hip_calib_config *c, int burn_in_only,
+                                            int32_t *status, uint64_t *iters) {
+    CHECK_S(s);
+    if (!c || first < 0 || count < 1 || first + count > s->cfg.n_chains)
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_chains: chains [%d,%d) outside [0,%d)", first,
+                    first + count, s->cfg.n_chains);
+    if (c->iter_readjust == 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "iter_readjust must be > 0");
+    if (count > s->calib_capacity) {
+        if (s->d_status)
+            hipFree(s->d_status);
+        if (s->d_iters)
+            hipFree(s->d_iters);
+        HIP_TRY(hipMalloc((void **)&s->d_status, count * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&s->d_iters, count * sizeof(u64)));
+        s->calib_capacity = count;
+    }
+    int rc;
+    CalibArgs a;
+    a.d = s->d;
+    a.sh = s->sh;
+    a.cur = s->cur;
+    a.first = first;
+    a.burn_in_only = burn_in_only ? 1 : 0;
+    a.cfg = *c;
+    a.status = s->d_status;
+    a.iters = s->d_iters;
+    rc = launch(s, K_CALIB, count, &a);
+    if (rc)
+        return rc;
+    std::vector<int> st(count);
+    std::vector<u64> it(count);
+    HIP_TRY(hipMemcpyAsync(st.data(), s->d_status, count * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(it.data(), s->d_iters, count * sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    int worst = 0;
+    for (int i = 0; i < count; i++) {
+        if (status)
+            status[i] = st[i];
+        if (iters)
+            iters[i] = it[i];
+        if (st[i] && !worst)
+            worst = st[i];
+    }
+    if (worst)
+        return fail(APEMOST_HIP_ERR_CALIBRATION, "calibration failed: %s",
+                    worst == 1 ? "a step width became too large" : "iteration limit reached");
+    return APEMOST_HIP_OK;
+}
+
+static int rng_device(int device) {
+    int rc = apemost_hip_device_info(device, nullptr, 0, nullptr, nullptr);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(device));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequence, uint64_t offset,
+                                   int32_t n, uint32_t *out) {
+    int rc = rng_device(device);
+    if (rc)
+        return rc;
+    if (n < 1 || !out)
+        return fail(APEMOST_HIP_ERR_INVALID, "rng_raw: bad arguments");
+    unsigned int *d;
+    HIP_TRY(hipMalloc((void **)&d, n * sizeof(unsigned int)));
+    hipLaunchKernelGGL(rng_raw_kernel, dim3(1), dim3(kWave), 0, 0, seed, subsequence, offset, n, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    hipFree(d);
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_rng_gaussian(int device, uint64_t seed, uint64_t subsequence, uint64_t offset,
+                                        double sigma, int32_t n, double *out, uint64_t *consumed) {
+    int rc = rng_device(device);
+    if (rc)
+        return rc;
+    if (n < 1 || !out)
+        return fail(APEMOST_HIP_ERR_INVALID, "rng_gaussian: bad arguments");
+    double *d;
+    u64 *dc;
+    HIP_TRY(hipMalloc((void **)&d, n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dc, sizeof(u64)));
+    hipLaunchKernelGGL(rng_gaussian_kernel, dim3(1), dim3(kWave), 0, 0, seed, subsequence, offset, sigma, n, d,
+                       dc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d, n * sizeof(double), hipMemcpyDeviceToHost));
+    u64 cons = 0;
+    HIP_TRY(hipMemcpy(&cons, dc, sizeof(u64), hipMemcpyDeviceToHost));
+    if (consumed)
+        *consumed = cons;
+    hipFree(d);
+    hipFree(dc);
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_timer_begin(apemost_hip_sampler *s) {
+    CHECK_S(s);
+    s->launches_at_begin = s->launches;
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_timer_end(apemost_hip_sampler *s, float *elapsed_ms, uint64_t *launches) {
+    CHECK_S(s);
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (elapsed_ms)
+        *elapsed_ms = ms;
+    if (launches)
+        *launches = s->launches - s->launches_at_begin;
+    return APEMOST_HIP_OK;
+}

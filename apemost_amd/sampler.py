@@ -1,0 +1,207 @@
+"""HipSampler: host-side mirror of the reference's parallel-tempering operators for one
+device shard, implemented entirely by calls into libapemost_hip.so (include/apemost_hip.h).
+
+Method names follow the reference functions they replace:
+  run_sampler            src/parallel_tempering.c:347-419
+  tempering_interaction  src/parallel_tempering_interaction.c:125-141 (fused into the next round)
+  calc_model             apps/<model>.c (device re-implementation)
+  markov_chain_calibrate src/markov_chain_calibrate.c:1182-1204
+  calibrate_first/rest   src/parallel_tempering.c:78-207
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .state import LadderState
+
+LADDER_CHEBYSHEV_BETA = 0
+
+
+def ladder_beta(kind, i, n_beta, beta_0):
+    """BETA_ALIGNMENT functions, src/parallel_tempering_beta.c:53-83 (host scalar math)."""
+    import math
+    d = n_beta - 1
+    if kind == 0:
+        return beta_0 + (1 - beta_0) / 2 * (1 - math.cos(i * math.pi / d))
+    if kind == 1:
+        return beta_0 + i * (1 - beta_0) / d
+    if kind == 2:
+        return 1 / (1 / beta_0 + i * (1 - 1 / beta_0) / d)
+    if kind == 3:
+        return 1 / (1 / beta_0 + (1 - 1 / beta_0) / 2 * (1 - math.cos(i * math.pi / d)))
+    if kind == 4:
+        return beta_0 + math.pow(i * 1.0 / d, 2) * (1 - beta_0)
+    if kind == 5:
+        return beta_0 + (1 - beta_0) * math.pow((1 - math.cos(i * math.pi / d)) / 2, 2)
+    if kind == 6:
+        return beta_0
+    raise ValueError("unknown ladder kind %r" % kind)
+
+
+def get_chain_beta(kind, i, n_beta, beta_0):
+    """get_chain_beta, src/parallel_tempering_beta.c:85-90: chain 0 is beta = 1."""
+    if n_beta == 1:
+        return 1.0
+    return ladder_beta(kind, n_beta - i - 1, n_beta, beta_0)
+
+
+def calc_beta_0(state, chain, stepwidth_factors):
+    """calc_beta_0, src/parallel_tempering_beta.c:92-102 (BETA_0_STEPWIDTH = 1.0)."""
+    r = (state.pmax[chain] - state.pmin[chain]) * 1.0
+    r = r / state.step[chain]
+    r = r / np.asarray(stepwidth_factors)
+    return float(np.max(r)) ** -0.5
+
+
+class HipSampler:
+    def __init__(self, model, n_par, n_chains, data, seed=0, device=0, chain_offset=0,
+                 n_chains_global=None, waves_per_chain=0, sigma=0.5, hmin=1e-6):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        assert data.ndim == 2
+        self.cfg = capi.Config(abi_version=capi.ABI_VERSION, device=device, model=model, n_par=n_par,
+                               n_chains=n_chains, n_data=data.shape[0], n_cols=data.shape[1],
+                               waves_per_chain=waves_per_chain, chain_offset=chain_offset,
+                               n_chains_global=n_chains if n_chains_global is None else n_chains_global,
+                               seed=seed, sigma=sigma, hmin=hmin)
+        self._h = C.c_void_p()
+        self.L = capi.lib()
+        capi.check(self.L.apemost_hip_create(C.byref(self.cfg), C.byref(self._h)))
+        capi.check(self.L.apemost_hip_set_data(self._h, data.ctypes.data_as(C.POINTER(C.c_double))))
+        self.n_par, self.n_chains = n_par, n_chains
+        self.n_chains_global = self.cfg.n_chains_global
+        self.chain_offset = chain_offset
+        self.seed = seed
+
+    def close(self):
+        if self._h:
+            self.L.apemost_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -----------------------------------------------------------------
+    def synchronize(self):
+        capi.check(self.L.apemost_hip_synchronize(self._h))
+
+    @property
+    def stream(self):
+        p = C.c_void_p()
+        capi.check(self.L.apemost_hip_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    @property
+    def geometry(self):
+        w, l = C.c_int(0), C.c_int(0)
+        capi.check(self.L.apemost_hip_waves_per_chain(self._h, C.byref(w), C.byref(l)))
+        return w.value, bool(l.value)
+
+    def set_state(self, state, fields=None):
+        v = state.view(fields) if fields else state.view()
+        capi.check(self.L.apemost_hip_set_state(self._h, C.byref(v)))
+
+    def get_state(self, state=None, fields=None):
+        state = state or LadderState(self.n_chains, self.n_par)
+        v = state.view(fields) if fields else state.view()
+        capi.check(self.L.apemost_hip_get_state(self._h, C.byref(v)))
+        return state
+
+    @property
+    def round(self):
+        r, p = C.c_uint64(0), C.c_int(0)
+        capi.check(self.L.apemost_hip_get_round(self._h, C.byref(r), C.byref(p)))
+        return r.value, bool(p.value)
+
+    def set_round(self, round_, swap_pending=False):
+        capi.check(self.L.apemost_hip_set_round(self._h, round_, int(swap_pending)))
+
+    # -- hot path -----------------------------------------------------------------
+    def calc_model(self, first=0, count=-1):
+        capi.check(self.L.apemost_hip_calc_model(self._h, first, count))
+
+    def loglike(self, params, beta):
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, self.n_par)
+        n = params.shape[0]
+        beta = np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.float64), (n,)))
+        prob, prior = np.zeros(n), np.zeros(n)
+        dp = C.POINTER(C.c_double)
+        capi.check(self.L.apemost_hip_loglike(self._h, n, params.ctypes.data_as(dp), beta.ctypes.data_as(dp),
+                                              prob.ctypes.data_as(dp), prior.ctypes.data_as(dp)))
+        return prob, prior
+
+    def launch_round(self, n_steps, apply_swap, d_samples=0):
+        capi.check(self.L.apemost_hip_launch_round(self._h, n_steps, int(apply_swap), d_samples))
+
+    def run_sampler(self, n_rounds, n_swap, d_samples=0):
+        """n_rounds x {n_swap steps per chain, one swap attempt}; asynchronous."""
+        capi.check(self.L.apemost_hip_run(self._h, n_rounds, n_swap, d_samples))
+
+    def edge_export(self, side, d_buf):
+        capi.check(self.L.apemost_hip_edge_export(self._h, side, d_buf))
+
+    def edge_import(self, side, d_buf):
+        capi.check(self.L.apemost_hip_edge_import(self._h, side, d_buf))
+
+    # -- calibration ----------------------------------------------------------------
+    def markov_chain_calibrate(self, first, count, cfg=None, burn_in_only=False):
+        cfg = cfg or capi.calib_defaults()
+        status = np.zeros(count, dtype=np.int32)
+        iters = np.zeros(count, dtype=np.uint64)
+        rc = self.L.apemost_hip_calibrate_chains(self._h, first, count, C.byref(cfg), int(burn_in_only),
+                                                 status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 iters.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc not in (capi.OK, capi.ERR_CALIBRATION):
+            capi.check(rc)
+        return status, iters
+
+    def calibrate_first(self, cfg=None):
+        """calibrate_first(): calc_model(chain 0) then markov_chain_calibrate(chain 0)."""
+        self.calc_model(0, 1)
+        status, _ = self.markov_chain_calibrate(0, 1, cfg)
+        return int(status[0])
+
+    def calibrate_rest(self, cfg=None, ladder_kind=LADDER_CHEBYSHEV_BETA, beta_0=-0.001,
+                       skip_calibrate_allchains=False):
+        """calibrate_rest() for a whole ladder on this device.  Entry state: chain 0 carries the
+        calibrated steps/params (read_calibration_file(chains, 1)), every beta = 1."""
+        assert self.n_chains == self.n_chains_global and self.chain_offset == 0
+        n_beta, n_par = self.n_chains, self.n_par
+        st = self.get_state()
+        factors = np.ones(n_par)
+
+        def prepare(i, beta, fac):
+            st.beta[i] = beta
+            st.swapcount[i] = 0
+            st.step[i] = st.step[0] * beta ** -0.5
+            if fac is not None:
+                st.step[i] = st.step[i] * fac
+            st.params[i] = st.params_best[0]
+
+        if n_beta > 1:
+            b0 = calc_beta_0(st, 0, factors) if beta_0 < 0 else beta_0
+            prepare(1, get_chain_beta(ladder_kind, 1, n_beta, b0), None)
+            self.set_state(st, ("beta", "swapcount", "step", "params"))
+            self.calc_model(1, 1)
+            status, _ = self.markov_chain_calibrate(1, 1, cfg)
+            if status[0]:
+                return int(status[0]), None, None
+            st = self.get_state()
+            factors = factors * st.beta[1] ** -0.5
+            factors = factors * st.step[0]
+            factors = factors / st.step[1]
+        if beta_0 < 0:
+            beta_0 = calc_beta_0(st, 0, factors)
+        if n_beta > 1:
+            for i in range(1, n_beta):
+                prepare(i, get_chain_beta(ladder_kind, i, n_beta, beta_0), factors)
+            self.set_state(st, ("beta", "swapcount", "step", "params"))
+            self.calc_model(1, n_beta - 1)
+            status, _ = self.markov_chain_calibrate(1, n_beta - 1, cfg, burn_in_only=skip_calibrate_allchains)
+            bad = status[status != 0]
+            if len(bad):
+                return int(bad[0]), beta_0, factors
+        return 0, beta_0, factors

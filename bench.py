@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- Metropolis steps/s (all chains) of the parallel-tempering hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
+rank per GPU over RCCL).  One bench "step" = one pass of the hot path over one batch:
+ROUNDS_PER_STEP rounds of {n_swap Metropolis steps per chain + one swap attempt}
+(run_sampler's loop body, src/parallel_tempering.c:392-409), sample rows written to HBM.
+Workload at every N: BASELINE config 2 per GPU -- simplesin, 128 chains x 1024 data points per
+GPU (weak scaling: the ladder has 128*N chains, block-partitioned over the ranks).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6  # fp64 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="simplesin")
+    ap.add_argument("--chains-per-gpu", type=int, default=128)
+    ap.add_argument("--n-data", type=int, default=1024)
+    ap.add_argument("--n-swap", type=int, default=0, help="0 = reference rule 2000/n_beta of the per-GPU ladder")
+    ap.add_argument("--rounds-per-step", type=int, default=32)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, st_template, n_swap, seconds):
+    """Times the CPU oracle (a port of the reference's algorithm with per-chain RNG streams and the
+    loop counter privatised) on all host cores, on a bounded sample of the workload."""
+    from oracle import oracle as orc
+    from tests.helpers import to_oracle
+    cores = len(os.sched_getaffinity(0))
+    lad = orc.Ladder(w.model, st_template.n_chain, w.n_par, w.data)
+    to_oracle(st_template, lad)
+    rng = orc.Rng(orc.RNG_STREAMS, 1, lad)
+    t0 = time.time()
+    orc.run_sampler(lad, rng, 8, n_swap, n_threads=cores)
+    per_round = max((time.time() - t0) / 8, 1e-6)
+    rounds = max(8, int(seconds / per_round))
+    t0 = time.time()
+    orc.run_sampler(lad, rng, rounds, n_swap, n_threads=cores)
+    dt = time.time() - t0
+    steps = rounds * n_swap * st_template.n_chain
+    return {"value": steps / dt, "unit": "Metropolis steps/s", "cores": cores, "kind": "port",
+            "sample": "%d rounds x %d steps x %d chains of the same workload in %.1f s (oracle, OpenMP over chains)"
+                      % (rounds, n_swap, st_template.n_chain, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (a.gpus, a.gpus))
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from apemost_amd import capi, workloads as wl
+    from apemost_amd.sampler import HipSampler, get_chain_beta
+    from apemost_amd.state import LadderState
+    from apemost_amd.distributed import HipShardEngine, ShardedLadder
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    n_local = a.chains_per_gpu
+    n_global = n_local * world
+    lo = rank * n_local
+    w = wl.by_name(a.workload, n_data=a.n_data, n_chain=n_global)
+    n_swap = a.n_swap or max(1, 2000 // n_local)
+    R = a.rounds_per_step
+
+    # a calibrated-looking ladder: chebyshev betas, steps = steps0 * beta^-1/2
+    st = LadderState.from_params(n_local, w.start, w.pmin, w.pmax, w.step * 0.3)
+    for i in range(n_local):
+        b = get_chain_beta(0, lo + i, n_global, 0.02)
+        st.beta[i] = b
+        st.step[i] = np.minimum(st.step[i] * b ** -0.5, w.pmax - w.pmin)
+
+    s = HipSampler(w.model, w.n_par, n_local, w.data, seed=2024, device=local_rank, chain_offset=lo,
+                   n_chains_global=n_global, waves_per_chain=a.waves)
+    s.set_state(st)
+    waves, lds = s.geometry
+    samples = None
+    if not a.no_samples:
+        samples = torch.zeros((R, n_swap, n_local, w.n_par + 2), dtype=torch.float64, device="cuda")
+    eng = HipShardEngine(s, torch)
+    ladder = ShardedLadder(eng, n_global, lo, n_local, rank, world, dist if world > 1 else None)
+
+    def one_step():
+        ladder.run_sampler(R, n_swap, samples)
+
+    def sync_all():
+        s.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    sync_all()
+    capi.check(s.L.apemost_hip_timer_begin(s._h))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    s.synchronize()
+    import ctypes as C
+    ev_ms, launches = C.c_float(0), C.c_uint64(0)
+    capi.check(s.L.apemost_hip_timer_end(s._h, C.byref(ev_ms), C.byref(launches)))
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_steps = a.steps * R * n_swap * n_global
+    value = total_steps / dt
+    # roofline of the dominant kernel (pt_round_kernel): ALGORITHMIC bytes per launch / avg launch duration
+    bytes_per_step = w.bytes_per_step()
+    launch_ms = ev_ms.value / max(launches.value, 1)
+    steps_per_launch = (a.steps * R * n_swap * n_local) / max(launches.value, 1)
+    achieved_gbs = bytes_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9
+    flops_per_step = {"simplesin": 28.0, "sine3": 3 * 24.0 + 4}.get(w.name, 40.0) * w.n_data
+    out = {
+        "metric": "MCMC steps/sec (all chains) on simplesin, 1/2/4/8 MI355X + HBM-roofline %",
+        "value": value, "unit": "Metropolis steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d beta-chains/GPU x %d GPU, %d data points, n_par=%d, n_swap=%d, "
+                               "%d rounds per bench step, sample rows %s" %
+                               (w.name, n_local, world, w.n_data, w.n_par, n_swap, R,
+                                "off" if a.no_samples else "on"),
+                   "chains_per_gpu": n_local, "n_data": w.n_data, "n_swap": n_swap, "rounds_per_step": R,
+                   "waves_per_chain": waves, "data_in_lds": lds, "parallelism": "ladder-sharded x%d" % world,
+                   "edge_exchanges_rank0": ladder.exchanges},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "pt_round_kernel", "launch_us": launch_ms * 1e3,
+                     "algorithmic_bytes_per_launch": bytes_per_step * steps_per_launch,
+                     "fp64_valu_frac": flops_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e12
+                                       / FP64_VALU_PEAK_TF},
+    }
+    if rank == 0:
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(w, st, n_swap, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

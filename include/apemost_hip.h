@@ -1,0 +1,217 @@
+/*
+ * apemost_hip.h -- C ABI of the MI355X (gfx950) parallel-tempering engine.
+ *
+ * This is the drop-in boundary for APEMoST's hot path: the body of
+ * run_sampler() (src/parallel_tempering.c:347-419), i.e. per chain
+ * markov_chain_step() (src/markov_chain.c:369-386) + mcmc_check_best()
+ * (src/mcmc_calculate.c:35-41) + sample output, then tempering_interaction()
+ * (src/parallel_tempering_interaction.c:125-141); and the calibration phases
+ * built from the same step (src/markov_chain.c:34-79,
+ * src/markov_chain_calibrate.c:1039-1204, src/parallel_tempering.c:78-207).
+ *
+ * Plain C: pointers, sizes, integers.  No torch / C++ types.  A reference
+ * maintainer binds it directly from C (INTEGRATION.md shows the patch to
+ * src/parallel_tempering.c); the Python host mirror binds it with ctypes.
+ *
+ * All chain state crosses the boundary as structure-of-arrays blocks
+ * (apemost_hip_state_view) -- the flattened form of the reference's `mcmc`
+ * struct (src/mcmc_struct.h:30-106) plus `parallel_tempering_mcmc`
+ * (src/parallel_tempering_beta.h:65-76).
+ *
+ * Every function returns APEMOST_HIP_OK (0) or a negative error code;
+ * apemost_hip_last_error() gives the message.  There is no CPU fallback: with
+ * no usable HIP device every compute entry point fails with
+ * APEMOST_HIP_ERR_NO_DEVICE.
+ */
+#ifndef APEMOST_HIP_H
+#define APEMOST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APEMOST_HIP_ABI_VERSION 1
+
+enum {
+    APEMOST_HIP_OK = 0,
+    APEMOST_HIP_ERR_INVALID = -1,   /* bad argument / shape mismatch */
+    APEMOST_HIP_ERR_NO_DEVICE = -2, /* no HIP device, or not gfx950 */
+    APEMOST_HIP_ERR_RUNTIME = -3,   /* a HIP call failed */
+    APEMOST_HIP_ERR_UNSUPPORTED = -4,
+    APEMOST_HIP_ERR_CALIBRATION = -5 /* calibration failed (reference: exit(1)) */
+};
+
+/* device-side likelihoods = re-implementations of the user plugins calc_model()
+ * (src/mcmc.h:164) of the BASELINE apps */
+enum {
+    APEMOST_MODEL_SIMPLESIN = 0,  /* apps/simplesin.c:12-38   n_par = 4            */
+    APEMOST_MODEL_PULSE = 1,      /* apps/pulse.c:12-54       n_par = 2 + 2*modes  */
+    APEMOST_MODEL_PULSE_VROT = 2, /* apps/pulse_vrot.c:12-65  n_par = 7            */
+    APEMOST_MODEL_SINE3 = 3       /* 10-parameter 3-sinusoid model  */
+};
+
+/* BETA_ALIGNMENT choices, src/parallel_tempering_beta.c:53-83 */
+enum {
+    APEMOST_LADDER_CHEBYSHEV_BETA = 0,
+    APEMOST_LADDER_EQUIDISTANT_BETA = 1,
+    APEMOST_LADDER_EQUIDISTANT_TEMPERATURE = 2,
+    APEMOST_LADDER_CHEBYSHEV_TEMPERATURE = 3,
+    APEMOST_LADDER_EQUIDISTANT_STEPWIDTH = 4,
+    APEMOST_LADDER_CHEBYSHEV_STEPWIDTH = 5,
+    APEMOST_LADDER_HOT_CHAINS = 6
+};
+
+#define APEMOST_HIP_MAX_PAR 62            /* n_par + 2 lanes of one wavefront */
+#define APEMOST_HIP_STREAMS_PER_CHAIN 256 /* rocRAND subsequence = chain*256 + slot */
+#define APEMOST_HIP_SWAP_SUBSEQUENCE 0x8000000000000000ULL
+
+typedef struct apemost_hip_sampler apemost_hip_sampler;
+
+typedef struct {
+    int32_t abi_version;     /* APEMOST_HIP_ABI_VERSION */
+    int32_t device;          /* HIP device ordinal */
+    int32_t model;           /* APEMOST_MODEL_* */
+    int32_t n_par;           /* get_n_par(), src/mcmc_gettersetter.c:174-183 */
+    int32_t n_chains;        /* chains resident on this device (a shard of the ladder) */
+    int32_t n_data;          /* m->data->size1 */
+    int32_t n_cols;          /* m->data->size2 (>= 2) */
+    int32_t waves_per_chain; /* wavefronts cooperating on one chain; 0 = choose */
+    int64_t chain_offset;    /* ladder index of local chain 0 */
+    int64_t n_chains_global; /* N_BETA, src/define_defaults.h:24-31 */
+    uint64_t seed;           /* rocRAND Philox4x32-10 seed (role of GSL_RNG_SEED) */
+    double sigma;            /* SIGMA, apps/simplesin.c:8-10 */
+    double hmin;             /* HMIN, apps/pulse.c:8-10 */
+} apemost_hip_config;
+
+/* Host-side structure-of-arrays view of n_chains chains; any pointer may be NULL
+ * (that field is skipped).  Shapes: [n_chains][n_par] or [n_chains]. */
+typedef struct {
+    double *params;           /* m->params */
+    double *params_best;      /* m->params_best */
+    double *step;             /* m->params_step */
+    double *pmin;             /* m->params_min */
+    double *pmax;             /* m->params_max */
+    uint64_t *params_accepts; /* m->params_accepts */
+    uint64_t *params_rejects; /* m->params_rejects */
+    double *beta;             /* parallel_tempering_mcmc.beta */
+    double *prob;             /* m->prob */
+    double *prior;            /* m->prior */
+    double *prob_best;        /* m->prob_best */
+    uint64_t *accept;         /* m->accept */
+    uint64_t *reject;         /* m->reject */
+    uint64_t *n_iter;         /* m->n_iter */
+    uint64_t *swapcount;      /* parallel_tempering_mcmc.swapcount */
+    uint64_t *rng_offsets;    /* [n_chains][n_par+1] 32-bit draws consumed per stream */
+} apemost_hip_state_view;
+
+/* calibration knobs: src/define_defaults.h:24-86, src/markov_chain.h:25-32 */
+typedef struct {
+    uint32_t burn_in_iterations; /* BURN_IN_ITERATIONS */
+    uint32_t iter_limit;         /* ITER_LIMIT */
+    uint32_t iter_readjust;      /* ITER_READJUST */
+    int32_t no_rescaling_limit;  /* NO_RESCALING_LIMIT */
+    double rat_limit;            /* desired_acceptance_rate argument */
+    double target_global;        /* TARGET_ACCEPTANCE_RATE */
+    double max_ar_deviation;     /* MAX_AR_DEVIATION */
+    double mul;                  /* MUL */
+    double adjust_step;          /* DEFAULT_ADJUST_STEP */
+} apemost_hip_calib_config;
+
+/* ---- environment ---------------------------------------------------------- */
+const char *apemost_hip_last_error(void);
+int apemost_hip_abi_version(void);
+int apemost_hip_device_count(int *count);
+/* name[] receives the gcnArchName; fails unless it is a gfx950 part */
+int apemost_hip_device_info(int device, char *name, size_t name_len, int *compute_units,
+                            uint64_t *hbm_bytes);
+
+/* ---- lifetime ------------------------------------------------------------- */
+int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sampler **out);
+int apemost_hip_destroy(apemost_hip_sampler *s);
+int apemost_hip_synchronize(apemost_hip_sampler *s);
+/* the HIP stream (hipStream_t) every launch of this sampler goes to */
+int apemost_hip_stream(apemost_hip_sampler *s, void **stream);
+int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, int *data_in_lds);
+
+/* ---- data and state (mcmc_load_data / setup_chains / read_calibration_file) */
+/* row-major [n_data][n_cols] host matrix, as gsl_matrix stores it */
+int apemost_hip_set_data(apemost_hip_sampler *s, const double *data_rowmajor);
+int apemost_hip_set_state(apemost_hip_sampler *s, const apemost_hip_state_view *v);
+int apemost_hip_get_state(apemost_hip_sampler *s, const apemost_hip_state_view *v);
+/* position of the swap stream = number of tempering_interaction() calls so far */
+int apemost_hip_set_round(apemost_hip_sampler *s, uint64_t round, int swap_pending);
+int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, int *swap_pending);
+
+/* ---- the hot path --------------------------------------------------------- */
+/* calc_model() for local chains [first, first+count) at their current params: prob,
+ * prior updated on device (src/parallel_tempering.c:88,147,185 call sites);
+ * count < 0 means every chain from `first` on */
+int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int32_t count);
+
+/* calc_model() at arbitrary points (apps/eval_main.c:52-66): n points, params
+ * [n][n_par], beta [n]; results to host arrays prob[n], prior[n] */
+int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params, const double *beta,
+                        double *prob, double *prior);
+
+/* One launch of the round kernel: optionally apply the pending swap attempt
+ * (tempering_interaction for swap-stream position `round`), then n_steps x
+ * {markov_chain_step, mcmc_check_best, n_iter++, sample row}.  d_samples is a
+ * DEVICE pointer to [n_steps][n_chains][n_par+2] doubles (params.., prob,
+ * prob-prior; the rows the reference prints to <name>-chain-<i>.prob.dump and
+ * prob-chain<i>.dump) or NULL.  Asynchronous on the sampler's stream.
+ * Sharded ladders call apemost_hip_edge_* around it; whole ladders use
+ * apemost_hip_run. */
+int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap,
+                             double *d_samples);
+
+/* run_sampler() for a ladder that lives entirely on this device: n_rounds x
+ * {n_swap steps, swap attempt}; the last swap is applied before returning
+ * control (still asynchronous).  d_samples: DEVICE [n_rounds*n_swap][n_chains][n_par+2] or NULL */
+int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32_t n_swap, double *d_samples);
+
+/* pair index `a` that tempering_interaction() will pick at swap-stream position
+ * `round` (parallel_tempering_decide_swap_now, interaction.c:87-97); -1 if n_global==1 */
+int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t n_chains_global);
+
+/* sharded ladders: the swap partner across a shard edge.  side 0 = lower
+ * neighbour (chain_offset-1), 1 = upper neighbour.  A record is
+ * apemost_hip_edge_doubles(n_par) doubles: beta, prob, prob_best,
+ * params[n_par], params_best[n_par].  d_buf is a DEVICE pointer (what RCCL
+ * sends/receives).  export packs this shard's edge chain; import fills the
+ * halo slot the next launch_round(apply_swap=1) reads. */
+int32_t apemost_hip_edge_doubles(int32_t n_par);
+int apemost_hip_edge_export(apemost_hip_sampler *s, int side, double *d_buf);
+int apemost_hip_edge_import(apemost_hip_sampler *s, int side, const double *d_buf);
+
+/* ---- calibration ---------------------------------------------------------- */
+void apemost_hip_calib_defaults(apemost_hip_calib_config *c);
+/* markov_chain_calibrate() (burn_in + calibrate_orig) on device for local chains
+ * [first, first+count); status[count] (host) receives 0 / 1 step too large /
+ * 2 iteration limit per chain, iters[count] the calibrate_orig sweep counts.
+ * With burn_in_only != 0 only burn_in() runs (-DSKIP_CALIBRATE_ALLCHAINS). */
+int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t count,
+                                 const apemost_hip_calib_config *c, int burn_in_only,
+                                 int32_t *status, uint64_t *iters);
+
+/* ---- test hooks: device RNG conformance ------------------------------------ */
+/* n raw 32-bit outputs of rocRAND philox4x32_10 (seed, subsequence, offset) */
+int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequence, uint64_t offset, int32_t n,
+                        uint32_t *out);
+/* n Gaussian proposals N(0,sigma) drawn the way the step kernel draws them;
+ * consumed receives the number of 32-bit draws used */
+int apemost_hip_rng_gaussian(int device, uint64_t seed, uint64_t subsequence, uint64_t offset,
+                             double sigma, int32_t n, double *out, uint64_t *consumed);
+
+/* ---- timing ---------------------------------------------------------------- */
+/* HIP events on the sampler's stream: begin/end bracket a region; elapsed ms and
+ * the number of round-kernel launches inside it */
+int apemost_hip_timer_begin(apemost_hip_sampler *s);
+int apemost_hip_timer_end(apemost_hip_sampler *s, float *elapsed_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APEMOST_HIP_H */

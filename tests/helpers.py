@@ -1,0 +1,54 @@
+"""Shared helpers for parity tests: build matching (device state, oracle ladder) pairs."""
+import numpy as np
+
+from apemost_amd import workloads as wl
+from apemost_amd.state import LadderState, ALL_FIELDS
+from oracle import oracle as orc
+
+
+def make_pair(w, n_chain, beta_0=0.02, seed=1234, chain_offset=0, n_global=None, init_prob=False):
+    """A calibrated-looking ladder: chebyshev betas, steps = step0 * beta^-1/2 (the
+    SKIP_CALIBRATE_ALLCHAINS prediction, src/parallel_tempering.c:190-196), identical in the
+    device mirror and the oracle."""
+    n_global = n_global or n_chain
+    st = LadderState.from_params(n_chain, w.start, w.pmin, w.pmax, w.step * 0.3)
+    for i in range(n_chain):
+        b = orc.get_chain_beta(orc.LADDER_CHEBYSHEV_BETA, chain_offset + i, n_global, beta_0)
+        st.beta[i] = b
+        st.step[i] = np.minimum(st.step[i] * b ** -0.5, (w.pmax - w.pmin))
+    lad = orc.Ladder(w.model, n_chain, w.n_par, w.data, chain_offset=chain_offset)
+    to_oracle(st, lad)
+    if init_prob:
+        for c in range(n_chain):
+            orc.calc_model(lad, c)
+        st.prob[:] = lad.prob
+        st.prior[:] = lad.prior
+    rng = orc.Rng(orc.RNG_STREAMS, seed, lad)
+    return st, lad, rng
+
+
+def to_oracle(st, lad):
+    for n in ALL_FIELDS:
+        if n != "rng_offsets":
+            getattr(lad, n)[...] = getattr(st, n)
+
+
+def assert_match(dev, lad, rng=None, rtol=1e-9, what=""):
+    """integer fields bit-exact, fp64 fields to rtol (sin/log differ by ulps between ocml and libm
+    and the device sums the data vector in tree order)."""
+    for n in ("accept", "reject", "n_iter", "swapcount", "params_accepts", "params_rejects"):
+        assert np.array_equal(getattr(dev, n), getattr(lad, n)), "%s %s" % (what, n)
+    if rng is not None:
+        assert np.array_equal(dev.rng_offsets, rng.offsets), what + " rng_offsets"
+    for n in ("params", "params_best", "step", "beta", "prob", "prior", "prob_best"):
+        np.testing.assert_allclose(getattr(dev, n), getattr(lad, n), rtol=rtol, atol=1e-300,
+                                   err_msg="%s %s" % (what, n))
+
+
+def small_workloads():
+    return {
+        "simplesin": wl.simplesin(n_data=256, n_chain=8),
+        "sine3": wl.sine3(n_data=300, n_chain=8),
+        "pulse": wl.pulse(n_data=257, n_chain=8),
+        "pulse_vrot": wl.pulse_vrot(n_data=200, n_chain=8),
+    }

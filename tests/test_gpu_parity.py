@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tolerances: integer state (counters, RNG positions, swap counts, pair indices) bit-exact;
+fp64 log-likelihoods rel 1e-12; trajectories rel 1e-9 (ulp-level sin/log/summation
+differences accumulate as a random walk over the steps)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from apemost_amd import capi, workloads as wl
+from apemost_amd.sampler import HipSampler
+from oracle import oracle as orc
+from tests.helpers import assert_match, make_pair, small_workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_device_is_gfx950():
+    name, cus, mem = capi.device_info(0)
+    assert name.startswith("gfx950") and cus >= 200 and mem > 200e9
+
+
+@pytest.mark.parametrize("seed,sub,off", [(0, 0, 0), (4357, 3 * 256 + 2, 5), (2 ** 63 + 11, 2 ** 63, 4 * 1000 + 1),
+                                          (0xdeadbeefdeadbeef, 2 ** 40 + 7, 2 ** 34 + 3)])
+def test_rocrand_stream_equals_oracle_philox(seed, sub, off):
+    dev = capi.rng_raw(seed, sub, off, 41)
+    ref = orc.philox_stream(seed, sub, 41, start=off)
+    assert np.array_equal(dev, ref)
+
+
+def test_gaussian_proposals_match_oracle():
+    w = wl.simplesin(n_data=8, n_chain=3)
+    lad = orc.Ladder(w.model, 3, 4, w.data)
+    rng = orc.Rng(orc.RNG_STREAMS, 77, lad)
+    st = lad.c_state()
+    L = orc.lib()
+    ref = np.array([L.orc_gaussian(C.byref(rng.c), C.byref(st), 2, 1, 0.37) for _ in range(500)])
+    dev, consumed = capi.rng_gaussian(77, 2 * 256 + 1, 0, 0.37, 500)
+    assert consumed == int(rng.offsets[2, 1])
+    np.testing.assert_allclose(dev, ref, rtol=1e-14)
+
+
+def test_swap_pair_host_matches_oracle():
+    for n in (2, 8, 128, 2048, 16384):
+        for r in range(50):
+            u = orc.philox_stream(5, 2 ** 63, 1, start=4 * r)[0] / 2 ** 32
+            assert capi.swap_pair(5, r, n) == orc.lib().orc_swap_pair_index(u, n)
+    assert capi.swap_pair(5, 0, 1) == -1
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
+def test_loglike_golden_vectors(waves, golden_dir):
+    # doc/manual.rst:190-213
+    data = np.array([[101, 0.67], [102, 1.01], [103, 7.9e-1], [104, 1.34]])
+    s = HipSampler(wl.MODEL_SIMPLESIN, 4, 1, data, waves_per_chain=waves)
+    prob, prior = s.loglike([[1, 0.2, 1, 0]], 1.0)
+    assert abs(prob[0] - (-1.480898044165363e+01)) < 1e-12 * 14.8 and prior[0] == 0
+    s.close()
+    # SURVEY 8(c) G1 on the reference's own light curve (tests/testlc.dat)
+    d = np.loadtxt(os.path.join(golden_dir, "testlc.dat"))
+    s = HipSampler(wl.MODEL_SIMPLESIN, 4, 1, d, waves_per_chain=waves)
+    prob, _ = s.loglike([[0.7, 5.2, 5.4, 0.0], [1.0, 10.0, 0.25, 0.1]], 1.0)
+    np.testing.assert_allclose(prob, [-3.187159885063915e+03, -3.271718790429034e+03], rtol=1e-12)
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
+@pytest.mark.parametrize("waves", [1, 4, 16])
+def test_loglike_matches_oracle(name, waves):
+    w = small_workloads()[name]
+    rs = np.random.RandomState(3)
+    n = 37
+    params = w.pmin + (w.pmax - w.pmin) * rs.uniform(0.05, 0.95, size=(n, w.n_par))
+    beta = rs.uniform(0.01, 1.0, n)
+    s = HipSampler(w.model, w.n_par, 2, w.data, waves_per_chain=waves)
+    prob, prior = s.loglike(params, beta)
+    ref = [orc.loglike(w.model, params[i], w.data, beta=beta[i]) for i in range(n)]
+    np.testing.assert_allclose(prob, [r[0] for r in ref], rtol=1e-12)
+    np.testing.assert_allclose(prior, [r[1] for r in ref], rtol=1e-13, atol=1e-300)
+    s.close()
+
+
+def test_loglike_ragged_and_tiny_inputs():
+    # n_data not a multiple of the wavefront, and smaller than one wavefront
+    for n_data in (1, 3, 63, 65, 1000):
+        w = wl.simplesin(n_data=n_data, n_chain=2)
+        for waves in (1, 8):
+            s = HipSampler(w.model, 4, 2, w.data, waves_per_chain=waves)
+            prob, _ = s.loglike([w.start], 0.5)
+            ref, _ = orc.loglike(w.model, w.start, w.data, beta=0.5)
+            assert abs(prob[0] - ref) <= 1e-12 * abs(ref)
+            s.close()
+
+
+def _run_both(w, n_chain, n_rounds, n_swap, waves, seed=42, init_prob=False):
+    torch = _torch()
+    st, lad, rng = make_pair(w, n_chain, seed=seed, init_prob=init_prob)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=seed, waves_per_chain=waves)
+    s.set_state(st)
+    d_samples = torch.zeros((n_rounds * n_swap, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
+    s.run_sampler(n_rounds, n_swap, d_samples.data_ptr())
+    s.synchronize()
+    dev = s.get_state()
+    ref_samples = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    return s, dev, d_samples.cpu().numpy(), lad, rng, ref_samples
+
+
+@pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
+@pytest.mark.parametrize("waves", [1, 4])
+def test_trajectory_matches_oracle(name, waves):
+    """every recorded step of every chain: same accept decisions, same swaps, same RNG positions"""
+    w = small_workloads()[name]
+    n_rounds, n_swap = 40, 25
+    s, dev, samples, lad, rng, ref = _run_both(w, 8, n_rounds, n_swap, waves)
+    assert_match(dev, lad, rng, what=name)
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    assert dev.swapcount.sum() > 0                      # swaps were exercised
+    assert 0 < dev.accept.sum() < dev.n_iter.sum()      # both accept and reject were exercised
+    r, pending = s.round
+    assert r == n_rounds and not pending
+    s.close()
+
+
+def test_first_step_always_accepted_quirk_q2():
+    # prob = -1e10 after read_calibration_file => first proposal accepted in every chain
+    w = small_workloads()["simplesin"]
+    s, dev, samples, lad, rng, ref = _run_both(w, 8, 1, 1, 1)
+    assert list(dev.accept) == [1] * 8 and list(dev.reject) == [0] * 8
+    assert_match(dev, lad, rng)
+    s.close()
+
+
+def test_run_in_pieces_equals_one_run():
+    """launch boundaries do not change the trajectory: 10 rounds == 4 + 6 rounds"""
+    torch = _torch()
+    w = small_workloads()["simplesin"]
+    st, _, _ = make_pair(w, 8)
+    outs = []
+    for split in ((10,), (4, 6)):
+        s = HipSampler(w.model, 4, 8, w.data, seed=9)
+        s.set_state(st)
+        for k in split:
+            s.run_sampler(k, 7)
+        s.synchronize()
+        outs.append(s.get_state())
+        s.close()
+    for n in ("params", "prob", "prob_best", "params_best", "accept", "swapcount", "rng_offsets"):
+        assert np.array_equal(getattr(outs[0], n), getattr(outs[1], n)), n
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 (128 chains x 1024 points): size-independent properties"""
+    torch = _torch()
+    w = wl.simplesin(n_data=1024, n_chain=128)
+    st, lad, rng = make_pair(w, 128, seed=7)
+    n_rounds, n_swap = 20, w.n_swap
+    outs = []
+    for rep in range(2):
+        s = HipSampler(w.model, 4, 128, w.data, seed=7)
+        s.set_state(st)
+        d = torch.zeros((n_rounds * n_swap, 128, 6), dtype=torch.float64, device="cuda")
+        s.run_sampler(n_rounds, n_swap, d.data_ptr())
+        s.synchronize()
+        outs.append((s.get_state(), d.cpu().numpy()))
+        s.close()
+    (a, sa), (b, sb) = outs
+    assert np.array_equal(sa, sb) and np.array_equal(a.params, b.params)      # run-to-run identical
+    assert np.all(a.accept + a.reject == n_rounds * n_swap) and np.all(a.n_iter == n_rounds * n_swap)
+    assert np.all(sa[..., :4] >= w.pmin) and np.all(sa[..., :4] <= w.pmax)   # proposals stay in bounds
+    assert np.all(a.prob_best >= a.prob)
+    assert a.swapcount.sum() <= n_rounds
+    # hot chains accept more than cold ones
+    assert a.accept[-8:].mean() > a.accept[:8].mean()
+    # and the oracle agrees on the whole thing
+    orc.run_sampler(lad, rng, n_rounds, n_swap, n_threads=8)
+    assert_match(a, lad, rng, what="config2")
+
+
+@pytest.mark.parametrize("name", ["simplesin", "pulse"])
+def test_calibration_matches_oracle(name):
+    w = small_workloads()[name]
+    n_chain = 4
+    st, lad, rng = make_pair(w, n_chain, seed=5, init_prob=True)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=5, waves_per_chain=2)
+    s.set_state(st)
+    dcfg = capi.calib_defaults(burn_in_iterations=600, iter_limit=20000)
+    ocfg = orc.calib_defaults(burn_in_iterations=600, iter_limit=20000)
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    dev = s.get_state()
+    for c in range(n_chain):
+        st_o, it_o = orc.markov_chain_calibrate(lad, rng, c, ocfg)
+        assert status[c] == st_o and iters[c] == it_o, (c, status[c], st_o, iters[c], it_o)
+    assert_match(dev, lad, rng, what="calibrate " + name)
+    s.close()
