@@ -70,6 +70,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as the system
+    # one this library links).  If torch is going to be used for device memory / RCCL plumbing it
+    # must be loaded FIRST so that the dynamic linker resolves our DT_NEEDED to the copy already
+    # in the process; two runtimes in one process cannot both open the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise ApemostHipError(ERR_NO_DEVICE, "%s not built; run `python -m apemost_amd.build`" % path)
