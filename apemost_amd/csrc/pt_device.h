@@ -35,17 +35,40 @@ constexpr double kTwoPi = 2.0 * 3.14159265358979323846264338328; // 2*M_PI, exac
 // rocRAND Philox4x32-10 stream with a draw counter (the counter is the only
 // RNG state kept in HBM between launches).
 // ---------------------------------------------------------------------------
+// rocRAND's engine indexes its 4-word result block with a run-time subscript, which
+// hipcc lowers to scratch (private) memory; this subclass keeps rocRAND's counter layout, key
+// schedule and ten_rounds() but selects the word with compares so the state stays in VGPRs.
+struct PhiloxRegs : public rocrand_device::philox4x32_10_engine {
+    __device__ __forceinline__ PhiloxRegs() {}
+    __device__ __forceinline__ void start(u64 seed, u64 subsequence, u64 offset) {
+        this->seed(seed, subsequence, offset);
+    }
+    __device__ __forceinline__ unsigned int next_word() {
+        const uint4 r = m_state.result;
+        const unsigned int ss = m_state.substate;
+        const unsigned int ret = ss == 0 ? r.x : (ss == 1 ? r.y : (ss == 2 ? r.z : r.w));
+        if (ss == 3) {
+            m_state.substate = 0;
+            this->discard_state();
+            m_state.result = this->ten_rounds(m_state.counter, m_state.key);
+        } else {
+            m_state.substate = ss + 1;
+        }
+        return ret;
+    }
+};
+
 struct Stream {
-    rocrand_state_philox4x32_10 st;
+    PhiloxRegs st;
     u64 n;
 
     __device__ __forceinline__ void init(u64 seed, u64 subsequence, u64 offset) {
-        rocrand_init(seed, subsequence, offset, &st);
+        st.start(seed, subsequence, offset);
         n = offset;
     }
     __device__ __forceinline__ unsigned int next() {
         n++;
-        return rocrand(&st);
+        return st.next_word();
     }
     // gsl_rng_uniform of a 32-bit generator: x / 2^32 in [0,1)
     __device__ __forceinline__ double uniform() { return next() * (1.0 / 4294967296.0); }
@@ -70,11 +93,31 @@ struct Stream {
     __device__ __forceinline__ double alog_uniform() { return log(uniform()); }
 };
 
+// Cross-lane moves on the DPP path (no LDS crossbar): the 64-bit value travels as two dwords.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double read_lane(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes, same value in every lane, fixed association:
+// pairs, quads, octets, rows of 16 (DPP quad_perm / row_half_mirror / row_mirror), then
+// (row0+row1)+(row2+row3) through scalar registers.
 __device__ __forceinline__ double wave_allreduce_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v += __shfl_xor(v, m, kWave);
-    return v;
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v); // row_half_mirror
+    v += dpp_move<0x140>(v); // row_mirror
+    const double r0 = read_lane(v, 0), r1 = read_lane(v, 16), r2 = read_lane(v, 32), r3 = read_lane(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src, kWave); }

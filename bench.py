@@ -40,12 +40,25 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 hardware threads but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(w, st_template, n_swap, seconds):
     """Times the CPU oracle (a port of the reference's algorithm with per-chain RNG streams and the
     loop counter privatised) on all host cores, on a bounded sample of the workload."""
     from oracle import oracle as orc
     from tests.helpers import to_oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     lad = orc.Ladder(w.model, st_template.n_chain, w.n_par, w.data)
     to_oracle(st_template, lad)
     rng = orc.Rng(orc.RNG_STREAMS, 1, lad)
