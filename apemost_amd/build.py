@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-HIP_LIB = os.path.join(HERE, "libapemost_hip.so")
+HIP_LIB = os.environ.get("APEMOST_HIP_LIB") or os.path.join(HERE, "libapemost_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
              "-Wno-unused-value"]
@@ -29,6 +29,17 @@ def build_hip(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     return HIP_LIB
+
+
+def build_stamps(verbose=False):
+    """diagnostic twin of the library with in-kernel s_memtime stamps (tools/stamp_profile.py)"""
+    out = os.path.join(HERE, "libapemost_hip_stamps.so")
+    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_STAMPS", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out,
+                                 os.path.join(CSRC, "apemost_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
 
 
 def build_all(force=False, verbose=False):

@@ -36,7 +36,7 @@ class StateView(C.Structure):
     _fields_ = [("params", _dp), ("params_best", _dp), ("step", _dp), ("pmin", _dp), ("pmax", _dp),
                 ("params_accepts", _up), ("params_rejects", _up), ("beta", _dp), ("prob", _dp),
                 ("prior", _dp), ("prob_best", _dp), ("accept", _up), ("reject", _up), ("n_iter", _up),
-                ("swapcount", _up), ("rng_offsets", _up)]
+                ("swapcount", _up), ("ticks", _up)]
 
 
 class CalibConfig(C.Structure):
@@ -55,7 +55,7 @@ EXPORTS = [
     "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_run", "apemost_hip_swap_pair",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_rng_raw",
-    "apemost_hip_rng_gaussian", "apemost_hip_timer_begin", "apemost_hip_timer_end",
+    "apemost_hip_rng_attempts", "apemost_hip_timer_begin", "apemost_hip_timer_end",
 ]
 
 _lib = None
@@ -112,8 +112,8 @@ def lib():
                                                C.POINTER(C.c_int32), _up]
     L.apemost_hip_rng_raw.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
                                       C.POINTER(C.c_uint32)]
-    L.apemost_hip_rng_gaussian.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double,
-                                           C.c_int32, _dp, _up]
+    L.apemost_hip_rng_attempts.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,
+                                           C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp]
     L.apemost_hip_timer_begin.argtypes = [vp]
     L.apemost_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float), _up]
     _lib = L
@@ -157,9 +157,10 @@ def rng_raw(seed, subsequence, offset, n, device=0):
     return out
 
 
-def rng_gaussian(seed, subsequence, offset, sigma, n, device=0):
-    out = np.zeros(n)
-    consumed = C.c_uint64(0)
-    check(lib().apemost_hip_rng_gaussian(device, seed, subsequence, offset, sigma, n,
-                                         out.ctypes.data_as(_dp), C.byref(consumed)))
-    return out, consumed.value
+def rng_attempts(seed, chain, slot, tick, q0, n, device=0):
+    y, s, valid = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
+    lu = C.c_double(0)
+    check(lib().apemost_hip_rng_attempts(device, seed, chain, slot, tick, q0, n, y.ctypes.data_as(_dp),
+                                         s.ctypes.data_as(_dp), valid.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         C.byref(lu)))
+    return y, s, valid.astype(bool), lu.value

@@ -31,7 +31,7 @@ struct RoundArgs {
 
 template <int MODEL, int WAVES, bool LDS_DATA>
 __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA> &e, const DevArrays &d,
-                                             const ChainShape &sh, double *lds) {
+                                             const ChainShape &sh, int c, double *lds) {
     constexpr int kThreads = WAVES * kWave;
     e.tid = threadIdx.x;
     e.lane = threadIdx.x & (kWave - 1);
@@ -39,10 +39,14 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA> &e, 
     e.n_par = sh.n_par;
     e.n_data = sh.n_data;
     e.consts = sh.consts;
+    e.seed = sh.seed;
+    e.g = (u64)(sh.chain_offset + c);
     e.parity = 0;
-    e.s_par = lds;                 // 2*64 doubles
-    e.s_part = lds + 2 * kWave;    // 2*16 doubles
-    double *s_data = lds + kFixedLdsDoubles; // [2*64 | 2*16 | 8 control] then the data vector
+    e.s_par = lds;              // 2*64 doubles
+    e.s_part = lds + 2 * kWave; // 2*16 doubles, then 8 control words
+    e.s_cand = (double2 *)(lds + kFixedLdsDoubles);
+    double *s_data = lds + kFixedLdsDoubles + WAVES * 2 * kWave;
+    e.setup_lanes();
     if (LDS_DATA) {
         // stage the data vector once per launch: coalesced HBM/L2 reads, SoA in LDS
         for (int i = e.tid; i < 2 * sh.n_data; i += kThreads)
@@ -66,24 +70,18 @@ __device__ __forceinline__ void chain_load(E &e, const DevArrays &d, const Chain
     e.prob = d.prob[cur][row];
     e.prior = d.prior[cur][row];
     e.prob_best = d.prob_best[cur][row];
-    e.beta = e.beta_all;
     e.accept = d.accept[c];
     e.reject = d.reject[c];
-    if (e.wave == 0) {
-        if (e.lane < n) {
-            const size_t k = (size_t)c * n + e.lane;
-            e.cur = d.params[cur][(size_t)row * n + e.lane];
-            e.best = d.params_best[cur][(size_t)row * n + e.lane];
-            e.stepw = d.step[k];
-            e.lo = d.pmin[k];
-            e.hi = d.pmax[k];
-            e.pacc = d.params_accepts[k];
-            e.prej = d.params_rejects[k];
-        }
-        if (e.lane <= n) {
-            const u64 subseq = (u64)(sh.chain_offset + c) * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)e.lane;
-            e.rng.init(sh.seed, subseq, d.rng_offsets[(size_t)c * (n + 1) + e.lane]);
-        }
+    e.tick = d.ticks[c];
+    if (e.wave == 0 && e.is_cand) {
+        const size_t k = (size_t)c * n + e.grp;
+        e.cur = d.params[cur][(size_t)row * n + e.grp];
+        e.best = d.params_best[cur][(size_t)row * n + e.grp];
+        e.stepw = d.step[k];
+        e.lo = d.pmin[k];
+        e.hi = d.pmax[k];
+        e.pacc = d.params_accepts[k];
+        e.prej = d.params_rejects[k];
     }
 }
 
@@ -93,23 +91,22 @@ __device__ __forceinline__ void chain_store(const E &e, const DevArrays &d, cons
     const int row = c + 1, n = sh.n_par;
     if (e.wave != 0)
         return;
-    if (e.lane < n) {
-        const size_t k = (size_t)c * n + e.lane;
-        d.params[dst][(size_t)row * n + e.lane] = e.cur;
-        d.params_best[dst][(size_t)row * n + e.lane] = e.best;
+    if (e.is_cand && e.qidx == 0) {
+        const size_t k = (size_t)c * n + e.grp;
+        d.params[dst][(size_t)row * n + e.grp] = e.cur;
+        d.params_best[dst][(size_t)row * n + e.grp] = e.best;
         d.params_accepts[k] = e.pacc;
         d.params_rejects[k] = e.prej;
         if (store_step)
             d.step[k] = e.stepw;
     }
-    if (e.lane <= n)
-        d.rng_offsets[(size_t)c * (n + 1) + e.lane] = e.rng.n;
-    if (e.lane == 0) {
+    if (e.lane == 63) {
         d.prob[dst][row] = e.prob;
         d.prior[dst][row] = e.prior;
         d.prob_best[dst][row] = e.prob_best;
         d.accept[c] = e.accept;
         d.reject[c] = e.reject;
+        d.ticks[c] = e.tick;
     }
 }
 
@@ -123,10 +120,9 @@ __device__ __forceinline__ void swap_in(E &e, const DevArrays &d, const ChainSha
                                         u64 round) {
     if (sh.n_global <= 1 || e.wave != 0)
         return;
-    Stream sw;
-    sw.init(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, 4 * round);
-    const double u = sw.uniform();
-    const double lc = sw.alog_uniform();
+    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, round);
+    const double u = u32_to_uniform(b.x);
+    const double lc = log(u32_to_uniform(b.y));
     const int nb = (int)sh.n_global;
     const long long a = (int)(nb * 1000 * u) % (nb - 1);
     const long long g = sh.chain_offset + c;
@@ -142,14 +138,14 @@ __device__ __forceinline__ void swap_in(E &e, const DevArrays &d, const ChainSha
     if (!(r > lc))
         return;
     // parallel_tempering_do_swap: params exchanged, prob is not (quirk Q1)
-    if (e.lane < n)
-        e.cur = d.params[cur][(size_t)partner * n + e.lane];
+    if (e.is_cand)
+        e.cur = d.params[cur][(size_t)partner * n + e.grp];
     const double a_best = d.prob_best[cur][row_a], b_best = d.prob_best[cur][row_b];
     const bool a_wins = a_best > b_best;
     if ((g == a) != a_wins) { // this chain receives the other one's best (quirk Q3)
         e.prob_best = a_wins ? a_best : b_best;
-        if (e.lane < n)
-            e.best = d.params_best[cur][(size_t)partner * n + e.lane];
+        if (e.is_cand)
+            e.best = d.params_best[cur][(size_t)partner * n + e.grp];
     }
     if (g == a && e.lane == 0)
         d.swapcount[c] += 1; // inc_swapcount(chains[candidate])
@@ -160,11 +156,14 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_round_kernel(const RoundArgs 
     extern __shared__ __align__(16) double lds[];
     Engine<MODEL, WAVES, LDS_DATA> e;
     const int c = blockIdx.x;
-    engine_setup(e, a.d, a.sh, lds);
+    engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
     if (a.apply_swap)
         swap_in(e, a.d, a.sh, c, a.cur, a.round);
     __syncthreads();
+#ifdef APEMOST_STAMPS
+    e.stamps_begin();
+#endif
 
     const int n = a.sh.n_par;
     for (unsigned s = 0; s < a.n_steps; s++) {
@@ -174,15 +173,18 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_round_kernel(const RoundArgs 
             if (a.samples) {
                 // the row the reference prints per step: params ("%.15e"), prob, prob-prior
                 double *row = a.samples + ((size_t)s * a.sh.n_chains + c) * (n + 2);
-                if (e.lane < n)
-                    row[e.lane] = e.cur;
-                else if (e.lane == n)
+                if (e.is_cand && e.qidx == 0)
+                    row[e.grp] = e.cur;
+                if (e.lane == 63) {
                     row[n] = e.prob;
-                else if (e.lane == n + 1)
                     row[n + 1] = e.prob - e.prior;
+                }
             }
         }
     }
+#ifdef APEMOST_STAMPS
+    e.stamps_flush();
+#endif
     if (e.wave == 0 && e.lane == 0)
         a.d.n_iter[c] += a.n_steps; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
     chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const Round
     extern __shared__ __align__(16) double lds[];
     Engine<MODEL, WAVES, LDS_DATA> e;
     const int c = a.first + blockIdx.x;
-    engine_setup(e, a.d, a.sh, lds);
+    engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
     __syncthreads();
     e.calc_model_current();
@@ -221,10 +223,10 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_loglike_kernel(const EvalArgs
     DevArrays d;
     d.data = a.data;
     const int c = blockIdx.x;
-    engine_setup(e, d, a.sh, lds);
-    e.beta_all = e.beta = a.beta[c];
+    engine_setup(e, d, a.sh, c, lds);
+    e.beta_all = a.beta[c];
     e.prior = 0;
-    e.cur = (e.wave == 0 && e.lane < a.sh.n_par) ? a.params[(size_t)c * a.sh.n_par + e.lane] : 0.0;
+    e.cur = (e.wave == 0 && e.is_cand) ? a.params[(size_t)c * a.sh.n_par + e.grp] : 0.0;
     __syncthreads();
     e.calc_model_current();
     if (e.wave == 0 && e.lane == 0) {
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calibrate_kernel(const CalibA
     Engine<MODEL, WAVES, LDS_DATA> e;
     const int c = a.first + blockIdx.x;
     const int n = a.sh.n_par;
-    engine_setup(e, a.d, a.sh, lds);
+    engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
     __syncthreads();
     const bool w0 = (e.wave == 0);
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calibrate_kernel(const CalibA
             int rescaled = 0, fail = 0;
             if (w0) {
                 int up = 0, clamped = 0, down = 0, too_large = 0;
-                if (e.lane < n) {
+                if (e.is_cand) {
                     const double ar = (double)e.pacc / ((double)e.prej + (double)e.pacc);
                     if (ar > rat_limit + 0.05) {
                         up = 1;
@@ -323,8 +325,9 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calibrate_kernel(const CalibA
                     }
                 }
                 for (int p = 0; p < n; p++) {
-                    const int up_p = __shfl(up, p, kWave), cl_p = __shfl(clamped, p, kWave);
-                    const int dn_p = __shfl(down, p, kWave), tl_p = __shfl(too_large, p, kWave);
+                    const int src = p * e.Q; // first lane of parameter p's group
+                    const int up_p = __shfl(up, src, kWave), cl_p = __shfl(clamped, src, kWave);
+                    const int dn_p = __shfl(down, src, kWave), tl_p = __shfl(too_large, src, kWave);
                     if (up_p) {
                         if (rescaled == 0)
                             rescaled = -1;
@@ -406,21 +409,23 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calibrate_kernel(const CalibA
 __global__ void rng_raw_kernel(u64 seed, u64 subseq, u64 offset, int n, unsigned int *out) {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
-    Stream s;
-    s.init(seed, subseq, offset);
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, subseq, offset, &st);
     for (int i = 0; i < n; i++)
-        out[i] = s.next();
+        out[i] = rocrand(&st);
 }
 
-__global__ void rng_gaussian_kernel(u64 seed, u64 subseq, u64 offset, double sigma, int n, double *out,
-                                    u64 *consumed) {
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
-    Stream s;
-    s.init(seed, subseq, offset);
-    for (int i = 0; i < n; i++)
-        out[i] = s.gaussian(sigma);
-    *consumed = s.n - offset;
+__global__ void rng_attempts_kernel(u64 seed, u64 chain, int slot, u64 tick, u64 q0, int n, double *y,
+                                    double *s, int *valid, double *log_u) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double yy, ss;
+        valid[i] = gaussian_attempt(seed, chain, slot, tick, q0 + (u64)i, yy, ss) ? 1 : 0;
+        y[i] = yy;
+        s[i] = ss;
+    }
+    if (i == 0)
+        *log_u = accept_log_uniform(seed, chain, slot, tick);
 }
 
 // edge records for sharded ladders: beta, prob, prob_best, params[n], params_best[n]
@@ -617,7 +622,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
         delete s;
         return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 8 or 16");
     }
-    const size_t fixed_lds = kFixedLdsDoubles * sizeof(double);
+    const size_t fixed_lds = (kFixedLdsDoubles + (size_t)s->waves * 2 * kWave) * sizeof(double);
     const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
     s->lds_data = fixed_lds + data_lds <= 160 * 1024 - 1024;
     s->lds_bytes = fixed_lds + (s->lds_data ? data_lds : 0);
@@ -639,7 +644,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
         (rc = dev_alloc(s, &d.params_accepts, n * np)) || (rc = dev_alloc(s, &d.params_rejects, n * np)) ||
         (rc = dev_alloc(s, &d.accept, n)) || (rc = dev_alloc(s, &d.reject, n)) ||
         (rc = dev_alloc(s, &d.n_iter, n)) || (rc = dev_alloc(s, &d.swapcount, n)) ||
-        (rc = dev_alloc(s, &d.rng_offsets, n * (np + 1))) ||
+        (rc = dev_alloc(s, &d.ticks, n)) ||
         (rc = dev_alloc(s, &data, (size_t)cfg->n_cols * cfg->n_data)))
         return rc;
     d.data = data;
@@ -757,7 +762,7 @@ static int xfer_state(apemost_hip_sampler *s, const apemost_hip_state_view *v, b
         (rc = xfer(s, (uint64_t *)d.reject, v->reject, 1, false, up)) ||
         (rc = xfer(s, (uint64_t *)d.n_iter, v->n_iter, 1, false, up)) ||
         (rc = xfer(s, (uint64_t *)d.swapcount, v->swapcount, 1, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.rng_offsets, v->rng_offsets, np + 1, false, up)))
+        (rc = xfer(s, (uint64_t *)d.ticks, v->ticks, 1, false, up)))
         return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return APEMOST_HIP_OK;
@@ -1157,29 +1162,45 @@ extern "C" int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequen
     return APEMOST_HIP_OK;
 }
 
-extern "C" int apemost_hip_rng_gaussian(int device, uint64_t seed, uint64_t subsequence, uint64_t offset,
-                                        double sigma, int32_t n, double *out, uint64_t *consumed) {
+extern "C" int apemost_hip_rng_attempts(int device, uint64_t seed, uint64_t chain, int32_t slot, uint64_t tick,
+                                        uint64_t q0, int32_t n, double *y, double *s, int32_t *valid,
+                                        double *accept_log_u) {
     int rc = rng_device(device);
     if (rc)
         return rc;
-    if (n < 1 || !out)
-        return fail(APEMOST_HIP_ERR_INVALID, "rng_gaussian: bad arguments");
-    double *d;
-    u64 *dc;
-    HIP_TRY(hipMalloc((void **)&d, n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dc, sizeof(u64)));
-    hipLaunchKernelGGL(rng_gaussian_kernel, dim3(1), dim3(kWave), 0, 0, seed, subsequence, offset, sigma, n, d,
-                       dc);
+    if (n < 1 || !y || !s || !valid)
+        return fail(APEMOST_HIP_ERR_INVALID, "rng_attempts: bad arguments");
+    double *dy, *ds, *dl;
+    int *dv;
+    HIP_TRY(hipMalloc((void **)&dy, n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&ds, n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dl, sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dv, n * sizeof(int)));
+    hipLaunchKernelGGL(rng_attempts_kernel, dim3((n + 63) / 64), dim3(kWave), 0, 0, seed, chain, slot, tick, q0, n,
+                       dy, ds, dv, dl);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d, n * sizeof(double), hipMemcpyDeviceToHost));
-    u64 cons = 0;
-    HIP_TRY(hipMemcpy(&cons, dc, sizeof(u64), hipMemcpyDeviceToHost));
-    if (consumed)
-        *consumed = cons;
-    hipFree(d);
-    hipFree(dc);
+    HIP_TRY(hipMemcpy(y, dy, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s, ds, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(valid, dv, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (accept_log_u)
+        HIP_TRY(hipMemcpy(accept_log_u, dl, sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(dy);
+    hipFree(ds);
+    hipFree(dl);
+    hipFree(dv);
     return APEMOST_HIP_OK;
 }
+
+#ifdef APEMOST_STAMPS
+// diagnostic build only: read and clear the per-segment cycle sums of workgroup 0
+extern "C" int apemost_hip_debug_stamps(unsigned long long *out16) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)));
+    unsigned long long zero[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero));
+    return APEMOST_HIP_OK;
+}
+#endif
 
 extern "C" int apemost_hip_timer_begin(apemost_hip_sampler *s) {
     CHECK_S(s);

@@ -11,7 +11,8 @@ F64_2D = ("params", "params_best", "step", "pmin", "pmax")
 U64_2D = ("params_accepts", "params_rejects")
 F64_1D = ("beta", "prob", "prior", "prob_best")
 U64_1D = ("accept", "reject", "n_iter", "swapcount")
-ALL_FIELDS = F64_2D + U64_2D + F64_1D + U64_1D + ("rng_offsets",)
+U64_1D = U64_1D + ("ticks",)
+ALL_FIELDS = F64_2D + U64_2D + F64_1D + U64_1D
 
 
 class LadderState:
@@ -27,7 +28,6 @@ class LadderState:
         self.prob = np.full(n_chain, -1e10)          # mcmc_init, src/mcmc.c:47
         self.prior = np.zeros(n_chain)
         self.prob_best = np.full(n_chain, -1e10)     # src/mcmc.c:49
-        self.rng_offsets = np.zeros((n_chain, n_par + 1), dtype=np.uint64)
 
     @classmethod
     def from_params(cls, n_chain, start, pmin, pmax, step):

@@ -65,7 +65,12 @@ enum {
 };
 
 #define APEMOST_HIP_MAX_PAR 62            /* n_par + 2 lanes of one wavefront */
-#define APEMOST_HIP_STREAMS_PER_CHAIN 256 /* rocRAND subsequence = chain*256 + slot */
+/* RNG addressing (rocRAND Philox4x32-10): stream (chain, slot) = subsequence chain*256+slot;
+ * attempt q of parameter p's proposal at tick t = block (t<<24)|q of slot p, words 0,1;
+ * accept uniform of tick t = word 0 of block t<<24 of slot n_par; swap attempt number r =
+ * block r of the swap subsequence (word 0 pair choice, word 1 accept). */
+#define APEMOST_HIP_STREAMS_PER_CHAIN 256
+#define APEMOST_HIP_TICK_SHIFT 24
 #define APEMOST_HIP_SWAP_SUBSEQUENCE 0x8000000000000000ULL
 
 typedef struct apemost_hip_sampler apemost_hip_sampler;
@@ -104,7 +109,7 @@ typedef struct {
     uint64_t *reject;         /* m->reject */
     uint64_t *n_iter;         /* m->n_iter */
     uint64_t *swapcount;      /* parallel_tempering_mcmc.swapcount */
-    uint64_t *rng_offsets;    /* [n_chains][n_par+1] 32-bit draws consumed per stream */
+    uint64_t *ticks;          /* [n_chains] Metropolis updates performed = RNG address of the next one */
 } apemost_hip_state_view;
 
 /* calibration knobs: src/define_defaults.h:24-86, src/markov_chain.h:25-32 */
@@ -200,10 +205,13 @@ int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t 
 /* n raw 32-bit outputs of rocRAND philox4x32_10 (seed, subsequence, offset) */
 int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequence, uint64_t offset, int32_t n,
                         uint32_t *out);
-/* n Gaussian proposals N(0,sigma) drawn the way the step kernel draws them;
- * consumed receives the number of 32-bit draws used */
-int apemost_hip_rng_gaussian(int device, uint64_t seed, uint64_t subsequence, uint64_t offset,
-                             double sigma, int32_t n, double *out, uint64_t *consumed);
+/* attempts q0..q0+n-1 of the proposal stream (chain, slot) at `tick`, exactly as the
+ * step kernel evaluates them: valid[i] says whether the polar pair is usable, and then
+ * the N(0,sigma) variate is (sigma*y[i])*s[i]; accept_log_u = ln(uniform) of the accept
+ * test of that tick when slot == n_par */
+int apemost_hip_rng_attempts(int device, uint64_t seed, uint64_t chain, int32_t slot, uint64_t tick,
+                             uint64_t q0, int32_t n, double *y, double *s, int32_t *valid,
+                             double *accept_log_u);
 
 /* ---- timing ---------------------------------------------------------------- */
 /* HIP events on the sampler's stream: begin/end bracket a region; elapsed ms and

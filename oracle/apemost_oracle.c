@@ -95,47 +95,64 @@ uint32_t orc_philox_at(uint64_t seed, uint64_t subsequence, uint64_t n) {
     return out[n & 3];
 }
 
-static uint32_t next_u32(orc_rng *r, const orc_state *s, int chain, int slot) {
-    r->draws++;
-    if (r->kind == ORC_RNG_GLOBAL_MT)
-        return orc_mt_next(&r->mt);
-    {
-        uint64_t *off = &r->offsets[(size_t)chain * (s->n_par + 1) + slot];
-        uint64_t subseq = (uint64_t)(s->chain_offset + chain) * ORC_STREAMS_PER_CHAIN + (uint64_t)slot;
-        return orc_philox_at(r->seed, subseq, (*off)++);
-    }
-}
-
 /* gsl_rng_uniform for mt19937: get()/2^32 in [0,1)  (src/mcmc_gettersetter.c:286-288) */
-double orc_uniform(orc_rng *r, const orc_state *s, int chain, int slot) {
-    return next_u32(r, s, chain, slot) / 4294967296.0;
+double orc_uniform(orc_rng *r) {
+    r->draws++;
+    return orc_mt_next(&r->mt) / 4294967296.0;
 }
 
-static double uniform_pos(orc_rng *r, const orc_state *s, int chain, int slot) {
+static double uniform_pos(orc_rng *r) {
     double x;
     do {
-        x = orc_uniform(r, s, chain, slot);
+        x = orc_uniform(r);
     } while (x == 0);
     return x;
 }
 
 /* gsl_ran_gaussian, polar Box-Muller, second variate discarded
  * (src/mcmc_gettersetter.c:290-305 default branch) */
-double orc_gaussian(orc_rng *r, const orc_state *s, int chain, int slot, double sigma) {
+double orc_gaussian(orc_rng *r, double sigma) {
     double x, y, r2;
     do {
-        x = -1 + 2 * uniform_pos(r, s, chain, slot);
-        y = -1 + 2 * uniform_pos(r, s, chain, slot);
+        x = -1 + 2 * uniform_pos(r);
+        y = -1 + 2 * uniform_pos(r);
         r2 = x * x + y * y;
     } while (r2 > 1.0 || r2 == 0);
     return sigma * y * sqrt(-2.0 * log(r2) / r2);
 }
 
+/* One attempt of the same polar method on a tick-addressed Philox block. */
+int orc_gaussian_attempt(uint64_t seed, uint64_t chain_global, int slot, uint64_t tick, uint64_t q,
+                         double *y_out, double *s_out) {
+    const uint64_t subseq = chain_global * ORC_STREAMS_PER_CHAIN + (uint64_t)slot;
+    const uint64_t block = (tick << ORC_TICK_SHIFT) | q;
+    const uint32_t w0 = orc_philox_at(seed, subseq, 4 * block + 0);
+    const uint32_t w1 = orc_philox_at(seed, subseq, 4 * block + 1);
+    const double x = -1 + 2 * (w0 / 4294967296.0);
+    const double y = -1 + 2 * (w1 / 4294967296.0);
+    const double r2 = x * x + y * y;
+    if (w0 == 0 || w1 == 0 || r2 > 1.0 || r2 == 0)
+        return 0;
+    *y_out = y;
+    *s_out = sqrt(-2.0 * log(r2) / r2);
+    return 1;
+}
+
 /* get_next_alog_urandom (src/mcmc_gettersetter.c:307-309).  Real GSL aborts on
  * log(0) (quirk Q8); the restatement defines ln 0 = -inf. */
-static double alog_urandom(orc_rng *r, const orc_state *s, int chain, int slot) {
-    double u = orc_uniform(r, s, chain, slot);
+double orc_accept_log_uniform(uint64_t seed, uint64_t chain_global, int n_par, uint64_t tick) {
+    const uint64_t subseq = chain_global * ORC_STREAMS_PER_CHAIN + (uint64_t)n_par;
+    const uint32_t w0 = orc_philox_at(seed, subseq, 4 * (tick << ORC_TICK_SHIFT));
+    const double u = w0 / 4294967296.0;
     return (u > 0) ? log(u) : -INFINITY;
+}
+
+static double alog_urandom(orc_rng *r, const orc_state *s, int chain) {
+    if (r->kind == ORC_RNG_GLOBAL_MT) {
+        double u = orc_uniform(r);
+        return (u > 0) ? log(u) : -INFINITY;
+    }
+    return orc_accept_log_uniform(r->seed, (uint64_t)(s->chain_offset + chain), s->n_par, r->ticks[chain]);
 }
 
 /* mod_double macro, src/mcmc_internal.h:46-48 */
@@ -282,9 +299,21 @@ static void do_step_for(orc_state *s, orc_rng *r, int c, int p) {
     const double step = s->step[k], old_value = s->params[k];
     const double max = s->pmax[k], min = s->pmin[k];
     double new_value;
-    do {
-        new_value = old_value + orc_gaussian(r, s, c, p, step);
-    } while (new_value > max || new_value < min);
+    if (r->kind == ORC_RNG_GLOBAL_MT) {
+        do {
+            new_value = old_value + orc_gaussian(r, step);
+        } while (new_value > max || new_value < min);
+    } else {
+        uint64_t q = 0;
+        for (;; q++) {
+            double y, sq;
+            if (!orc_gaussian_attempt(r->seed, (uint64_t)(s->chain_offset + c), p, r->ticks[c], q, &y, &sq))
+                continue;
+            new_value = old_value + step * y * sq;
+            if (!(new_value > max || new_value < min))
+                break;
+        }
+    }
     s->params[k] = new_value;
 }
 
@@ -300,7 +329,7 @@ int orc_check_accept(double prob_old, double prob_new, orc_rng *r, const orc_sta
         return 1;
     if (drew)
         *drew = 1;
-    return alog_urandom(r, s, chain, s->n_par) < (prob_new - prob_old) ? 1 : 0;
+    return alog_urandom(r, s, chain) < (prob_new - prob_old) ? 1 : 0;
 }
 
 /* markov_chain_step: src/markov_chain.c:369-386 ; counters
@@ -327,6 +356,8 @@ void orc_markov_chain_step(orc_state *s, orc_rng *r, int c) {
         for (p = 0; p < n; p++)
             s->params_rejects[(size_t)c * n + p]++;
     }
+    if (r->kind == ORC_RNG_STREAMS)
+        r->ticks[c]++;
 }
 
 /* markov_chain_step_for: src/markov_chain.c:317-333 (calc_model_for of every
@@ -344,6 +375,8 @@ void orc_markov_chain_step_for(orc_state *s, orc_rng *r, int c, int p) {
         s->params[k] = old_value;
         s->params_rejects[k]++;
     }
+    if (r->kind == ORC_RNG_STREAMS)
+        r->ticks[c]++;
 }
 
 /* mcmc_check_best: src/mcmc_calculate.c:35-41 */
@@ -466,7 +499,6 @@ int orc_tempering_interaction(orc_state *s, orc_rng *r, double *trace) {
         u = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 0) / 4294967296.0;
         u2 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 1) / 4294967296.0;
         r->round++;
-        r->draws += 2;
         if (n_beta == 1)
             return -1;
     } else {

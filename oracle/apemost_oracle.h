@@ -47,11 +47,18 @@ enum {
 /* ---- RNG ----------------------------------------------------------------
  * ORC_RNG_GLOBAL_MT : the reference's single process-global gsl mt19937
  *                     (src/mcmc.c:27-35), consumed in program order.
- * ORC_RNG_STREAMS   : counter-based Philox4x32-10 streams laid out the way the
- *                     device engine uses rocRAND: stream (chain c, slot s) has
- *                     subsequence c*256+s; slot p<n_par feeds the proposal of
- *                     parameter p, slot n_par feeds the accept test; the swap
- *                     stream is subsequence 2^63, position 4*round.
+ * ORC_RNG_STREAMS   : counter-based Philox4x32-10 streams addressed the way the
+ *                     device engine addresses rocRAND: stream (chain c, slot s)
+ *                     is subsequence c*256+s.  Every Metropolis update of a
+ *                     chain has a tick t (0,1,2,.. per chain).  Attempt q of
+ *                     the proposal of parameter p at tick t is Philox block
+ *                     (t<<24)|q of slot p: words 0,1 are the polar pair; an
+ *                     attempt fails if a word is 0, the polar test rejects, or
+ *                     the proposal leaves [min,max]; the first successful q
+ *                     wins (same law as the reference's redraw loops).  The
+ *                     accept uniform of tick t is word 0 of block t<<24 of slot
+ *                     n_par.  The swap stream is subsequence 2^63, block = round
+ *                     (word 0 pair choice, word 1 accept).
  */
 enum { ORC_RNG_GLOBAL_MT = 0, ORC_RNG_STREAMS = 1 };
 
@@ -69,12 +76,13 @@ uint32_t orc_philox_at(uint64_t seed, uint64_t subsequence, uint64_t n);
 
 #define ORC_STREAMS_PER_CHAIN 256
 #define ORC_SWAP_SUBSEQUENCE 0x8000000000000000ULL
+#define ORC_TICK_SHIFT 24
 
 typedef struct {
     int kind;            /* ORC_RNG_* */
     orc_mt19937 mt;      /* GLOBAL_MT state */
     uint64_t seed;       /* STREAMS: philox key */
-    uint64_t *offsets;   /* STREAMS: [n_chain][n_par+1] draws consumed per stream */
+    uint64_t *ticks;     /* STREAMS: [n_chain] Metropolis updates performed so far */
     uint64_t round;      /* STREAMS: swap-stream position */
     uint64_t draws;      /* statistics: total 32-bit draws consumed */
 } orc_rng;
@@ -126,8 +134,14 @@ void orc_calib_defaults(orc_calib_cfg *c);
 enum { ORC_CALIB_OK = 0, ORC_CALIB_STEP_TOO_LARGE = 1, ORC_CALIB_ITER_LIMIT = 2 };
 
 /* ---- API ------------------------------------------------------------------ */
-double orc_uniform(orc_rng *r, const orc_state *s, int chain, int slot);
-double orc_gaussian(orc_rng *r, const orc_state *s, int chain, int slot, double sigma);
+/* GLOBAL_MT only: gsl_rng_uniform / gsl_ran_gaussian on the global stream */
+double orc_uniform(orc_rng *r);
+double orc_gaussian(orc_rng *r, double sigma);
+/* STREAMS: attempt q of (global chain, slot) at tick t.  Returns 1 if the polar
+ * pair is usable; then the N(0,sigma) variate is (sigma*y)*s_out */
+int orc_gaussian_attempt(uint64_t seed, uint64_t chain_global, int slot, uint64_t tick, uint64_t q,
+                         double *y_out, double *s_out);
+double orc_accept_log_uniform(uint64_t seed, uint64_t chain_global, int n_par, uint64_t tick);
 
 double orc_loglike(int model, int n_par, const double *params, const double *data,
                    int n_data, int n_cols, double beta, double sigma, double hmin,

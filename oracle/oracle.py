@@ -29,7 +29,7 @@ class _MT(C.Structure):
 
 
 class _Rng(C.Structure):
-    _fields_ = [("kind", C.c_int), ("mt", _MT), ("seed", C.c_uint64), ("offsets", _up),
+    _fields_ = [("kind", C.c_int), ("mt", _MT), ("seed", C.c_uint64), ("ticks", _up),
                 ("round", C.c_uint64), ("draws", C.c_uint64)]
 
 
@@ -77,10 +77,14 @@ def lib():
         L.orc_philox_at.restype = C.c_uint32
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_uint32)]
-        L.orc_uniform.argtypes = [C.POINTER(_Rng), C.POINTER(_State), C.c_int, C.c_int]
+        L.orc_uniform.argtypes = [C.POINTER(_Rng)]
         L.orc_uniform.restype = C.c_double
-        L.orc_gaussian.argtypes = [C.POINTER(_Rng), C.POINTER(_State), C.c_int, C.c_int, C.c_double]
+        L.orc_gaussian.argtypes = [C.POINTER(_Rng), C.c_double]
         L.orc_gaussian.restype = C.c_double
+        L.orc_gaussian_attempt.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, _dp, _dp]
+        L.orc_gaussian_attempt.restype = C.c_int
+        L.orc_accept_log_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+        L.orc_accept_log_uniform.restype = C.c_double
         L.orc_loglike.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
                                   C.c_double, C.c_double, _dp]
         L.orc_loglike.restype = C.c_double
@@ -201,14 +205,14 @@ class Rng:
     def __init__(self, kind, seed=0, ladder=None):
         self.c = _Rng()
         self.c.kind = kind
-        self.offsets = None
+        self.ticks = None
         if kind == RNG_GLOBAL_MT:
             lib().orc_mt_seed(C.byref(self.c.mt), seed)
         else:
             assert ladder is not None
             self.c.seed = seed
-            self.offsets = np.zeros((ladder.n_chain, ladder.n_par + 1), dtype=np.uint64)
-            self.c.offsets = self.offsets.ctypes.data_as(_up)
+            self.ticks = np.zeros(ladder.n_chain, dtype=np.uint64)
+            self.c.ticks = self.ticks.ctypes.data_as(_up)
 
     @property
     def round(self):
@@ -237,6 +241,16 @@ def philox_block(ctr, key):
 def philox_stream(seed, subsequence, n, start=0):
     L = lib()
     return np.array([L.orc_philox_at(seed, subsequence, start + i) for i in range(n)], dtype=np.uint32)
+
+
+def gaussian_attempt(seed, chain_global, slot, tick, q):
+    y, sq = C.c_double(0), C.c_double(0)
+    ok = lib().orc_gaussian_attempt(seed, chain_global, slot, tick, q, C.byref(y), C.byref(sq))
+    return bool(ok), y.value, sq.value
+
+
+def accept_log_uniform(seed, chain_global, n_par, tick):
+    return lib().orc_accept_log_uniform(seed, chain_global, n_par, tick)
 
 
 def loglike(model, params, data, beta=1.0, sigma=0.5, hmin=1e-6):

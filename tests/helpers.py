@@ -29,7 +29,7 @@ def make_pair(w, n_chain, beta_0=0.02, seed=1234, chain_offset=0, n_global=None,
 
 def to_oracle(st, lad):
     for n in ALL_FIELDS:
-        if n != "rng_offsets":
+        if n != "ticks":
             getattr(lad, n)[...] = getattr(st, n)
 
 
@@ -39,7 +39,7 @@ def assert_match(dev, lad, rng=None, rtol=1e-9, what=""):
     for n in ("accept", "reject", "n_iter", "swapcount", "params_accepts", "params_rejects"):
         assert np.array_equal(getattr(dev, n), getattr(lad, n)), "%s %s" % (what, n)
     if rng is not None:
-        assert np.array_equal(dev.rng_offsets, rng.offsets), what + " rng_offsets"
+        assert np.array_equal(dev.ticks, rng.ticks), what + " ticks"
     for n in ("params", "params_best", "step", "beta", "prob", "prior", "prob_best"):
         np.testing.assert_allclose(getattr(dev, n), getattr(lad, n), rtol=rtol, atol=1e-300,
                                    err_msg="%s %s" % (what, n))

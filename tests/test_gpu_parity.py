@@ -35,16 +35,18 @@ def test_rocrand_stream_equals_oracle_philox(seed, sub, off):
     assert np.array_equal(dev, ref)
 
 
-def test_gaussian_proposals_match_oracle():
-    w = wl.simplesin(n_data=8, n_chain=3)
-    lad = orc.Ladder(w.model, 3, 4, w.data)
-    rng = orc.Rng(orc.RNG_STREAMS, 77, lad)
-    st = lad.c_state()
-    L = orc.lib()
-    ref = np.array([L.orc_gaussian(C.byref(rng.c), C.byref(st), 2, 1, 0.37) for _ in range(500)])
-    dev, consumed = capi.rng_gaussian(77, 2 * 256 + 1, 0, 0.37, 500)
-    assert consumed == int(rng.offsets[2, 1])
-    np.testing.assert_allclose(dev, ref, rtol=1e-14)
+def test_gaussian_attempts_match_oracle():
+    seed, chain, slot, tick = 77, 5, 1, 123456789
+    y, s, valid, _ = capi.rng_attempts(seed, chain, slot, tick, 3, 400)
+    ref = [orc.gaussian_attempt(seed, chain, slot, tick, 3 + i) for i in range(400)]
+    assert list(valid) == [r[0] for r in ref]
+    assert 0.7 < valid.mean() < 0.87                       # polar acceptance pi/4
+    ok = valid
+    np.testing.assert_allclose(y[ok], [r[1] for r in ref if r[0]], rtol=0)   # exact: integer -> fp64
+    np.testing.assert_allclose(s[ok], [r[2] for r in ref if r[0]], rtol=1e-14)
+    for t in (0, 1, 2 ** 30 + 17):
+        _, _, _, lu = capi.rng_attempts(seed, chain, 4, t, 0, 1)
+        assert abs(lu - orc.accept_log_uniform(seed, chain, 4, t)) <= 1e-14 * abs(lu)
 
 
 def test_swap_pair_host_matches_oracle():
@@ -151,7 +153,7 @@ def test_run_in_pieces_equals_one_run():
         s.synchronize()
         outs.append(s.get_state())
         s.close()
-    for n in ("params", "prob", "prob_best", "params_best", "accept", "swapcount", "rng_offsets"):
+    for n in ("params", "prob", "prob_best", "params_best", "accept", "swapcount", "ticks"):
         assert np.array_equal(getattr(outs[0], n), getattr(outs[1], n)), n
 
 

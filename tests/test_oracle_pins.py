@@ -29,21 +29,19 @@ def test_mt19937_default_seed_stream():
 
 
 def test_uniform_and_gaussian_kats():
-    lad = orc.Ladder(orc.MODEL_SIMPLESIN, 1, 4, np.zeros((1, 2)))
     rng = orc.Rng(orc.RNG_GLOBAL_MT, 0)
-    st = lad.c_state()
     import ctypes as C
     L = orc.lib()
-    u = [L.orc_uniform(C.byref(rng.c), C.byref(st), 0, 0) for _ in range(3)]
+    u = [L.orc_uniform(C.byref(rng.c)) for _ in range(3)]
     assert u == [4293858116 / 2 ** 32, 699692587 / 2 ** 32, 1213834231 / 2 ** 32]
     assert abs(u[0] - 0.999741748906672) < 1e-15
     # SURVEY 8(c) probe values (polar method, second variate discarded)
     rng = orc.Rng(orc.RNG_GLOBAL_MT, 0)
-    g = [L.orc_gaussian(C.byref(rng.c), C.byref(st), 0, 0, 1.0) for _ in range(3)]
+    g = [L.orc_gaussian(C.byref(rng.c), 1.0) for _ in range(3)]
     np.testing.assert_allclose(g, [0.1339186081186759, -0.088100991831438394, 1.6744084062537739],
                                rtol=1e-14)
     assert rng.c.draws == 10
-    nxt = math.log(L.orc_uniform(C.byref(rng.c), C.byref(st), 0, 0))
+    nxt = math.log(L.orc_uniform(C.byref(rng.c)))
     assert abs(nxt - (-0.27451079819355362)) < 1e-15
 
 
@@ -61,6 +59,25 @@ def test_philox_random123_kats():
     seed, sub, blk = 0xa4093822 | (0x299f31d0 << 32), 0x13198a2e | (0x03707344 << 32), 0x1243f6a88
     assert list(orc.philox_stream(seed, sub, 4, start=4 * blk)) == \
         orc.philox_block([blk & 0xffffffff, blk >> 32, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
+
+
+def test_tick_addressed_attempts_follow_the_polar_method():
+    """STREAMS mode: attempt q at tick t is Philox block (t<<24)|q; same transform as gsl_ran_gaussian"""
+    import math
+    seed, chain, slot, tick = 9, 3, 2, 77
+    n_ok = 0
+    for q in range(200):
+        ok, y, s = orc.gaussian_attempt(seed, chain, slot, tick, q)
+        w = orc.philox_stream(seed, chain * 256 + slot, 2, start=4 * ((tick << 24) | q))
+        x, yy = -1 + 2 * (int(w[0]) / 2 ** 32), -1 + 2 * (int(w[1]) / 2 ** 32)
+        r2 = x * x + yy * yy
+        assert ok == (w[0] != 0 and w[1] != 0 and 0 < r2 <= 1.0)
+        if ok:
+            n_ok += 1
+            assert y == yy and abs(s - math.sqrt(-2.0 * math.log(r2) / r2)) <= 1e-15 * s
+    assert 130 < n_ok < 185
+    w0 = orc.philox_stream(seed, chain * 256 + 4, 1, start=4 * (tick << 24))[0]
+    assert orc.accept_log_uniform(seed, chain, 4, tick) == math.log(int(w0) / 2 ** 32)
 
 
 def test_simplesin_manual_eval_kat():

@@ -52,6 +52,7 @@ def test_streams_mode_is_thread_count_invariant():
         lad.beta[:] = [orc.get_chain_beta(0, i, 6, 0.05) for i in range(6)]
         rng = orc.Rng(orc.RNG_STREAMS, 99, lad)
         s = orc.run_sampler(lad, rng, 20, 7, record=True, n_threads=threads)
-        out.append((s, lad.params.copy(), lad.accept.copy(), lad.swapcount.copy(), rng.offsets.copy()))
+        out.append((s, lad.params.copy(), lad.accept.copy(), lad.swapcount.copy(), rng.ticks.copy()))
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+    assert list(out[0][4]) == [140] * 6     # one tick per Metropolis update
