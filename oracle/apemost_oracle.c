@@ -545,6 +545,74 @@ static void run_chain_round(orc_state *s, orc_rng *r, int c, uint64_t round, uns
     }
 }
 
+void orc_run_steps(orc_state *s, orc_rng *r, unsigned int n_steps, double *samples, int n_threads) {
+    int c;
+    if (r->kind == ORC_RNG_STREAMS && n_threads > 1) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+        for (c = 0; c < s->n_chain; c++) {
+            orc_rng local = *r;
+            run_chain_round(s, &local, c, 0, n_steps, samples);
+        }
+    } else {
+        for (c = 0; c < s->n_chain; c++)
+            run_chain_round(s, r, c, 0, n_steps, samples);
+    }
+}
+
+/* tempering_interaction on one shard of a block-partitioned ladder: same pair choice,
+ * criterion and do_swap as above (src/parallel_tempering_interaction.c:25-42,87-141), the
+ * partner across a shard edge comes from a halo record */
+int orc_tempering_interaction_shard(orc_state *s, orc_rng *r, int64_t n_global, const double *halo_lo,
+                                    const double *halo_hi, int *swapped_out) {
+    const int n = s->n_par;
+    const int64_t lo = s->chain_offset, hi = s->chain_offset + s->n_chain;
+    double u, u2, c, rr;
+    int64_t a;
+    int swapped = 0;
+    if (swapped_out)
+        *swapped_out = 0;
+    u = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 0) / 4294967296.0;
+    u2 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 1) / 4294967296.0;
+    r->round++;
+    if (n_global <= 1)
+        return -1;
+    a = orc_swap_pair_index(u, (int)n_global);
+    c = (u2 > 0) ? log(u2) : -INFINITY;
+    if (a >= lo && a + 1 < hi) { /* both local */
+        int la = (int)(a - lo);
+        swapped = orc_swap_decision(s->beta[la], s->beta[la + 1], s->prob[la], s->prob[la + 1], c, &rr);
+        if (swapped) {
+            do_swap(s, la);
+            s->swapcount[la]++;
+        }
+    } else if (a == lo - 1 || a == hi - 1) { /* straddles an edge of this shard */
+        const int mine_is_a = (a == hi - 1);
+        const int lc = mine_is_a ? s->n_chain - 1 : 0;
+        const double *h = mine_is_a ? halo_hi : halo_lo;
+        const double h_beta = h[0], h_prob = h[1], h_best = h[2];
+        const double *h_params = h + 3, *h_params_best = h + 3 + n;
+        double a_beta = mine_is_a ? s->beta[lc] : h_beta, b_beta = mine_is_a ? h_beta : s->beta[lc];
+        double a_prob = mine_is_a ? s->prob[lc] : h_prob, b_prob = mine_is_a ? h_prob : s->prob[lc];
+        double a_best = mine_is_a ? s->prob_best[lc] : h_best, b_best = mine_is_a ? h_best : s->prob_best[lc];
+        swapped = orc_swap_decision(a_beta, b_beta, a_prob, b_prob, c, &rr);
+        if (swapped) {
+            const int a_wins = a_best > b_best;
+            memcpy(s->params + (size_t)lc * n, h_params, sizeof(double) * n);
+            if (mine_is_a != a_wins) { /* this chain receives the other one's best */
+                s->prob_best[lc] = a_wins ? a_best : b_best;
+                memcpy(s->params_best + (size_t)lc * n, h_params_best, sizeof(double) * n);
+            }
+            if (mine_is_a)
+                s->swapcount[lc]++;
+        }
+    }
+    if (swapped_out)
+        *swapped_out = swapped;
+    return (int)a;
+}
+
 void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n_swap,
                      double *samples, int n_threads) {
     uint64_t round;

@@ -167,6 +167,16 @@ int orc_swap_decision(double a_beta, double b_beta, double a_prob, double b_prob
                       double log_u, double *r_out);
 int orc_swap_pair_index(double u, int n_beta);
 
+/* Sharded ladders (the engine's multi-GPU layout): this state holds chains
+ * [chain_offset, chain_offset+n_chain) of an n_global ladder.  Applies swap attempt number
+ * r->round to the local chains; halo_lo / halo_hi are the edge records (beta, prob, prob_best,
+ * params[n_par], params_best[n_par]) of chains chain_offset-1 and chain_offset+n_chain, needed
+ * only when the chosen pair straddles that edge (else may be NULL).  Returns the pair index a. */
+int orc_tempering_interaction_shard(orc_state *s, orc_rng *r, int64_t n_global, const double *halo_lo,
+                                    const double *halo_hi, int *swapped_out);
+/* n_steps x {markov_chain_step, check_best, n_iter++} for every local chain, no swap */
+void orc_run_steps(orc_state *s, orc_rng *r, unsigned int n_steps, double *samples, int n_threads);
+
 /* samples: [n_rounds*n_swap][n_chain][n_par+2] = params.., prob, prob-prior ; may be NULL.
  * n_threads > 1 is only meaningful with ORC_RNG_STREAMS. */
 void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n_swap,

@@ -112,6 +112,10 @@ def lib():
         L.orc_swap_pair_index.restype = C.c_int
         L.orc_run_sampler.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.c_uint64, C.c_uint,
                                       _dp, C.c_int]
+        L.orc_run_steps.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.c_uint, _dp, C.c_int]
+        L.orc_tempering_interaction_shard.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.c_int64, _dp, _dp,
+                                                      C.POINTER(C.c_int)]
+        L.orc_tempering_interaction_shard.restype = C.c_int
         L.orc_burn_in.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.c_int, C.c_uint]
         L.orc_calib_defaults.argtypes = [C.POINTER(CalibCfg)]
         for name in ("orc_calibrate_orig", "orc_markov_chain_calibrate"):
@@ -271,6 +275,26 @@ def run_sampler(ladder, rng, n_rounds, n_swap, record=False, n_threads=1):
         ptr = samples.ctypes.data_as(_dp)
     lib().orc_run_sampler(C.byref(st), C.byref(rng.c), n_rounds, n_swap, ptr, n_threads)
     return samples
+
+
+def run_steps(ladder, rng, n_steps, record=False, n_threads=1):
+    st = ladder.c_state()
+    samples, ptr = None, None
+    if record:
+        samples = np.zeros((n_steps, ladder.n_chain, ladder.n_par + 2))
+        ptr = samples.ctypes.data_as(_dp)
+    lib().orc_run_steps(C.byref(st), C.byref(rng.c), n_steps, ptr, n_threads)
+    return samples
+
+
+def tempering_interaction_shard(ladder, rng, n_global, halo_lo=None, halo_hi=None):
+    st = ladder.c_state()
+    sw = C.c_int(0)
+    as_p = lambda h: None if h is None else np.ascontiguousarray(h, dtype=np.float64).ctypes.data_as(_dp)
+    keep = [None if h is None else np.ascontiguousarray(h, dtype=np.float64) for h in (halo_lo, halo_hi)]
+    ptrs = [None if k is None else k.ctypes.data_as(_dp) for k in keep]
+    a = lib().orc_tempering_interaction_shard(C.byref(st), C.byref(rng.c), n_global, ptrs[0], ptrs[1], C.byref(sw))
+    return a, bool(sw.value)
 
 
 def step(ladder, rng, chain):

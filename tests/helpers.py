@@ -52,3 +52,42 @@ def small_workloads():
         "pulse": wl.pulse(n_data=257, n_chain=8),
         "pulse_vrot": wl.pulse_vrot(n_data=200, n_chain=8),
     }
+
+
+class OracleShardEngine:
+    """ShardedLadder engine backed by the CPU oracle (test infrastructure): lets the sharding and
+    edge-exchange host logic run under gloo without a GPU.  Same interface as HipShardEngine."""
+
+    def __init__(self, lad, seed, n_global, torch):
+        import contextlib
+        self.lad, self.n_global, self.torch, self.seed = lad, n_global, torch, seed
+        self.rng = orc.Rng(orc.RNG_STREAMS, seed, lad)
+        self.halo = {0: None, 1: None}
+        self._null = contextlib.nullcontext
+
+    def swap_pair(self, round_):
+        if self.n_global <= 1:
+            return -1
+        u = orc.philox_stream(self.seed, 2 ** 63, 1, start=4 * round_)[0] / 2 ** 32
+        return orc.lib().orc_swap_pair_index(u, self.n_global)
+
+    def comm_stream(self):
+        return self._null()
+
+    def edge_export(self, side):
+        c = 0 if side == 0 else self.lad.n_chain - 1
+        rec = np.concatenate([[self.lad.beta[c], self.lad.prob[c], self.lad.prob_best[c]],
+                              self.lad.params[c], self.lad.params_best[c]])
+        return self.torch.from_numpy(rec.copy())
+
+    def edge_import(self, side, buf):
+        self.halo[side] = buf.numpy().copy()
+
+    def launch_round(self, n_steps, apply_swap, samples):
+        if apply_swap:
+            orc.tempering_interaction_shard(self.lad, self.rng, self.n_global, self.halo[0], self.halo[1])
+            self.halo = {0: None, 1: None}
+        if n_steps:
+            out = orc.run_steps(self.lad, self.rng, n_steps, record=samples is not None)
+            if samples is not None:
+                samples[...] = self.torch.from_numpy(out)

@@ -201,3 +201,52 @@ def test_calibration_matches_oracle(name):
         assert status[c] == st_o and iters[c] == it_o, (c, status[c], st_o, iters[c], it_o)
     assert_match(dev, lad, rng, what="calibrate " + name)
     s.close()
+
+
+@pytest.mark.parametrize("split", [4, 3])
+def test_two_device_shards_equal_whole_ladder(split):
+    """edge_export / edge_import / halo swap-in on the device: a ladder cut into two shards (both on
+    this GPU, driven in lock step like two ranks would) must reproduce the whole-ladder run bit for bit"""
+    torch = _torch()
+    from apemost_amd.distributed import HipShardEngine
+    w = small_workloads()["pulse"]
+    n_global, n_rounds, n_swap, seed = 8, 80, 3, 17
+    st, _, _ = make_pair(w, n_global, seed=seed)
+    whole = HipSampler(w.model, w.n_par, n_global, w.data, seed=seed)
+    whole.set_state(st)
+    whole.run_sampler(n_rounds, n_swap)
+    whole.synchronize()
+    ref = whole.get_state()
+    whole.close()
+
+    bounds = [(0, split), (split, n_global)]
+    shards = []
+    for lo, hi in bounds:
+        s = HipSampler(w.model, w.n_par, hi - lo, w.data, seed=seed, chain_offset=lo, n_chains_global=n_global)
+        s.set_state(st.slice(lo, hi))
+        shards.append(HipShardEngine(s, torch))
+    exchanges, pending, rnd = 0, False, 0
+    for r in range(n_rounds + 1):
+        n_steps = n_swap if r < n_rounds else 0
+        if pending:
+            a = shards[0].swap_pair(rnd)
+            assert a == shards[1].swap_pair(rnd)
+            if a == split - 1:
+                up, down = shards[0].edge_export(1), shards[1].edge_export(0)
+                for e in shards:
+                    e.s.synchronize()
+                shards[0].edge_import(1, down)
+                shards[1].edge_import(0, up)
+                exchanges += 1
+            rnd += 1
+        for e in shards:
+            e.launch_round(n_steps, pending, None)
+        pending = n_steps > 0
+    got = [e.s.get_state() for e in shards]
+    for e in shards:
+        e.s.close()
+    assert exchanges > 0
+    for f in ("params", "params_best", "prob", "prob_best", "prior", "accept", "reject", "swapcount", "ticks",
+              "n_iter"):
+        assert np.array_equal(np.concatenate([getattr(g, f) for g in got]), getattr(ref, f)), f
+    assert ref.swapcount.sum() > 0
