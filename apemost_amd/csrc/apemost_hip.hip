@@ -23,6 +23,7 @@ struct RoundArgs {
     ChainShape sh;
     int cur;          // which half of the double-buffered fields is current
     int first;        // first local chain (calc_model on a range)
+    int which;        // -1: all-parameter updates; p: update parameter p only (markov_chain_step_for)
     int apply_swap;   // fuse tempering_interaction() for swap-stream position `round`
     unsigned n_steps; // Metropolis steps in this launch
     u64 round;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_round_kernel(const RoundArgs 
 
     const int n = a.sh.n_par;
     for (unsigned s = 0; s < a.n_steps; s++) {
-        e.step(-1);
+        e.step(a.which);
         if (e.wave == 0) {
             e.check_best();
             if (a.samples) {
@@ -712,6 +713,15 @@ extern "C" int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, i
     return APEMOST_HIP_OK;
 }
 
+extern "C" int apemost_hip_set_chain_offset(apemost_hip_sampler *s, int64_t chain_offset) {
+    CHECK_S(s);
+    if (chain_offset < 0 || chain_offset + s->cfg.n_chains > s->cfg.n_chains_global)
+        return fail(APEMOST_HIP_ERR_INVALID, "chain offset %lld outside the ladder", (long long)chain_offset);
+    s->cfg.chain_offset = chain_offset;
+    s->sh.chain_offset = chain_offset;
+    return APEMOST_HIP_OK;
+}
+
 extern "C" int apemost_hip_set_data(apemost_hip_sampler *s, const double *data_rowmajor) {
     CHECK_S(s);
     if (!data_rowmajor)
@@ -874,6 +884,7 @@ extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int
     a.sh = s->sh;
     a.cur = s->cur;
     a.first = first;
+    a.which = -1;
     a.apply_swap = 0;
     a.n_steps = 0;
     a.round = 0;
@@ -975,8 +986,23 @@ static int enable_big_lds(apemost_hip_sampler *s) {
     return APEMOST_HIP_OK;
 }
 
+static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap, int which,
+                             double *d_samples);
+
 extern "C" int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap,
                                         double *d_samples) {
+    return launch_round_impl(s, n_steps, apply_swap, -1, d_samples);
+}
+
+extern "C" int apemost_hip_launch_round_for(apemost_hip_sampler *s, uint32_t n_steps, int32_t param,
+                                            double *d_samples) {
+    if (s && (param < 0 || param >= s->cfg.n_par))
+        return fail(APEMOST_HIP_ERR_INVALID, "launch_round_for: parameter %d outside [0,%d)", param, s->cfg.n_par);
+    return launch_round_impl(s, n_steps, 0, param, d_samples);
+}
+
+static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap, int which,
+                             double *d_samples) {
     CHECK_S(s);
     int rc;
     RoundArgs a;
@@ -984,6 +1010,7 @@ extern "C" int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps
     a.sh = s->sh;
     a.cur = s->cur;
     a.first = 0;
+    a.which = which;
     a.apply_swap = apply_swap ? 1 : 0;
     a.n_steps = n_steps;
     a.round = s->round;
@@ -997,7 +1024,7 @@ extern "C" int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps
         s->round++;
         s->swap_pending = 0;
     }
-    if (n_steps > 0)
+    if (n_steps > 0 && which < 0)
         s->swap_pending = 1;
     return APEMOST_HIP_OK;
 }
@@ -1018,6 +1045,34 @@ extern "C" int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32
     }
     if (s->swap_pending)
         return apemost_hip_launch_round(s, 0, 1, nullptr);
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_samples_alloc(apemost_hip_sampler *s, uint64_t n_steps, double **d_samples) {
+    CHECK_S(s);
+    if (!d_samples || n_steps == 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "samples_alloc: bad arguments");
+    const size_t bytes = (size_t)n_steps * s->cfg.n_chains * (s->cfg.n_par + 2) * sizeof(double);
+    HIP_TRY(hipMalloc((void **)d_samples, bytes));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_samples_read(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
+                                        double *host) {
+    CHECK_S(s);
+    if (!d_samples || !host)
+        return fail(APEMOST_HIP_ERR_INVALID, "samples_read: bad arguments");
+    const size_t bytes = (size_t)n_steps * s->cfg.n_chains * (s->cfg.n_par + 2) * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(host, d_samples, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_samples_free(apemost_hip_sampler *s, double *d_samples) {
+    CHECK_S(s);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (d_samples)
+        HIP_TRY(hipFree(d_samples));
     return APEMOST_HIP_OK;
 }
 

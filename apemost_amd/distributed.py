@@ -52,6 +52,22 @@ class ShardedLadder:
             self.e.edge_import(side, recv)
         self.exchanges += 1
 
+    def prime(self):
+        """Exchange one dummy record with each neighbour so that the communicator and its P2P
+        channels exist before anything is timed (RCCL creates them lazily on first use)."""
+        if self.dist is None or self.world == 1:
+            return
+        dist = self.dist
+        with self.e.comm_stream():
+            for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
+                if peer < 0 or peer >= self.world:
+                    continue
+                send = self.e.edge_export(side)
+                recv = send.new_empty(send.shape)
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer),
+                                                   dist.P2POp(dist.irecv, recv, peer)]):
+                    req.wait()
+
     def launch_round(self, n_steps, samples=None):
         if self.swap_pending:
             self._exchange_if_edge()

@@ -1,0 +1,308 @@
+/* Bridge: host chain objects <-> device engine (see apemost_bridge.h). */
+#include <math.h>
+#include <string.h>
+#include "apemost_bridge.h"
+#include "parallel_tempering_beta.h"
+#include "debug.h"
+
+#ifndef SIGMA
+#define SIGMA 0.5
+#endif
+#ifndef HMIN
+#define HMIN 1e-6
+#endif
+
+unsigned long apemost_swap_round = 0;
+
+struct apemost_ladder {
+    mcmc **chains;
+    unsigned int n, n_par;
+    apemost_hip_sampler *s;
+    apemost_hip_state_view v; /* host staging arrays, structure of arrays */
+};
+
+void apemost_hip_or_die(int rc, const char *what) {
+    if (rc == APEMOST_HIP_OK)
+        return;
+    fflush(stdout);
+    fprintf(stderr, "APEMoST MI355X engine: %s failed (%d): %s\n", what, rc, apemost_hip_last_error());
+    fprintf(stderr, "This build has no CPU path for the sampler; a gfx950 GPU is required.\n");
+    exit(1);
+}
+
+static unsigned long env_seed(void) {
+    const char *s = getenv("APEMOST_SEED");
+    if (s == NULL)
+        s = getenv("GSL_RNG_SEED");
+    return s ? strtoul(s, NULL, 0) : 0;
+}
+
+static parallel_tempering_mcmc *pt(const mcmc *m) { return (parallel_tempering_mcmc *)m->additional_data; }
+
+static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned int n_chains, long chain_offset,
+                                           long n_global) {
+    apemost_hip_config cfg;
+    apemost_hip_sampler *s = NULL;
+    const char *dev = getenv("APEMOST_DEVICE"), *waves = getenv("APEMOST_WAVES");
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = APEMOST_HIP_ABI_VERSION;
+    cfg.device = dev ? atoi(dev) : 0;
+    cfg.model = model;
+    cfg.n_par = (int)m->n_par;
+    cfg.n_chains = (int)n_chains;
+    cfg.n_data = (int)m->data->size1;
+    cfg.n_cols = (int)m->data->size2;
+    cfg.waves_per_chain = waves ? atoi(waves) : 0;
+    cfg.chain_offset = chain_offset;
+    cfg.n_chains_global = n_global;
+    cfg.seed = env_seed();
+    cfg.sigma = SIGMA;
+    cfg.hmin = HMIN;
+    apemost_hip_or_die(apemost_hip_create(&cfg, &s), "apemost_hip_create");
+    if (m->data->tda != m->data->size2) {
+        fprintf(stderr, "data matrix must be contiguous\n");
+        exit(1);
+    }
+    apemost_hip_or_die(apemost_hip_set_data(s, m->data->data), "apemost_hip_set_data");
+    return s;
+}
+
+static int model_fits(int model, unsigned int n_par) {
+    switch (model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        return n_par == 4;
+    case APEMOST_MODEL_SINE3:
+        return n_par == 10;
+    case APEMOST_MODEL_PULSE:
+        return n_par >= 4 && (n_par - 2) % 2 == 0;
+    case APEMOST_MODEL_PULSE_VROT:
+        return n_par == 7;
+    }
+    return 0;
+}
+
+static const char *model_name(int model) {
+    static const char *names[] = {"simplesin", "pulse", "pulse_vrot", "sine3"};
+    return (model >= 0 && model < 4) ? names[model] : "?";
+}
+
+/* The user's likelihood is host C and cannot run on the GPU; the engine carries device
+ * re-implementations of the BASELINE models.  Find the one that reproduces the linked
+ * calc_model() at a handful of points inside the prior box, or stop. */
+#define DETECT_POINTS 6
+int apemost_detect_model(mcmc *m) {
+    static int cached = -1;
+    static unsigned int cached_npar = 0;
+    const unsigned int n = m->n_par;
+    const char *forced = getenv("APEMOST_DEVICE_MODEL");
+    double *pts, *beta, host_prob[DETECT_POINTS], host_prior[DETECT_POINTS], dev_prob[DETECT_POINTS],
+        dev_prior[DETECT_POINTS];
+    gsl_vector *saved;
+    double saved_prob, saved_prior;
+    unsigned int j, p;
+    int model, found = -1;
+
+    if (cached >= 0 && cached_npar == n)
+        return cached;
+    pts = (double *)malloc(sizeof(double) * DETECT_POINTS * n);
+    beta = (double *)malloc(sizeof(double) * DETECT_POINTS);
+    saved = gsl_vector_alloc(n);
+    gsl_vector_memcpy(saved, m->params);
+    saved_prob = m->prob;
+    saved_prior = m->prior;
+    for (j = 0; j < DETECT_POINTS; j++) {
+        for (p = 0; p < n; p++) {
+            const double lo = gsl_vector_get(m->params_min, p), hi = gsl_vector_get(m->params_max, p);
+            double frac = (j + 1) * 0.6180339887498949 * (p + 1) + 0.137 * p;
+            frac -= floor(frac);
+            pts[j * n + p] = lo + (hi - lo) * (0.05 + 0.9 * frac);
+            gsl_vector_set(m->params, p, pts[j * n + p]);
+        }
+        beta[j] = pt(m) ? get_beta(m) : 1.0;
+        calc_model(m, NULL);
+        host_prob[j] = m->prob;
+        host_prior[j] = m->prior;
+    }
+    gsl_vector_memcpy(m->params, saved);
+    gsl_vector_free(saved);
+    m->prob = saved_prob;
+    m->prior = saved_prior;
+
+    for (model = 0; model < 4 && found < 0; model++) {
+        apemost_hip_sampler *s;
+        int ok = 1;
+        if (!model_fits(model, n))
+            continue;
+        if (forced && strcmp(forced, model_name(model)) != 0)
+            continue;
+        s = create_sampler(m, model, 1, 0, 1);
+        apemost_hip_or_die(apemost_hip_loglike(s, DETECT_POINTS, pts, beta, dev_prob, dev_prior),
+                           "apemost_hip_loglike");
+        apemost_hip_destroy(s);
+        for (j = 0; j < DETECT_POINTS; j++) {
+            const double scale = fabs(host_prob[j]) > 1 ? fabs(host_prob[j]) : 1;
+            if (!(fabs(dev_prob[j] - host_prob[j]) <= 1e-9 * scale))
+                ok = 0;
+            if (model == APEMOST_MODEL_PULSE || model == APEMOST_MODEL_PULSE_VROT)
+                if (!(fabs(dev_prior[j] - host_prior[j]) <= 1e-9 * (fabs(host_prior[j]) + 1)))
+                    ok = 0;
+        }
+        if (ok)
+            found = model;
+    }
+    free(pts);
+    free(beta);
+    if (found < 0) {
+        fprintf(stderr,
+                "APEMoST MI355X engine: the linked calc_model() (%u parameters) matches none of the device\n"
+                "likelihoods (simplesin, pulse, pulse_vrot, sine3; SIGMA=%g HMIN=%g).  Device models must\n"
+                "reproduce the host plugin to 1e-9; refusing to sample a different posterior.\n",
+                n, (double)SIGMA, (double)HMIN);
+        exit(1);
+    }
+    IFDEBUG printf("device likelihood: %s\n", model_name(found));
+    cached = found;
+    cached_npar = n;
+    return found;
+}
+
+static void alloc_view(apemost_ladder *l) {
+    const size_t n = l->n, np = l->n_par;
+    apemost_hip_state_view *v = &l->v;
+    v->params = (double *)calloc(n * np, sizeof(double));
+    v->params_best = (double *)calloc(n * np, sizeof(double));
+    v->step = (double *)calloc(n * np, sizeof(double));
+    v->pmin = (double *)calloc(n * np, sizeof(double));
+    v->pmax = (double *)calloc(n * np, sizeof(double));
+    v->params_accepts = (uint64_t *)calloc(n * np, sizeof(uint64_t));
+    v->params_rejects = (uint64_t *)calloc(n * np, sizeof(uint64_t));
+    v->beta = (double *)calloc(n, sizeof(double));
+    v->prob = (double *)calloc(n, sizeof(double));
+    v->prior = (double *)calloc(n, sizeof(double));
+    v->prob_best = (double *)calloc(n, sizeof(double));
+    v->accept = (uint64_t *)calloc(n, sizeof(uint64_t));
+    v->reject = (uint64_t *)calloc(n, sizeof(uint64_t));
+    v->n_iter = (uint64_t *)calloc(n, sizeof(uint64_t));
+    v->swapcount = (uint64_t *)calloc(n, sizeof(uint64_t));
+    v->ticks = (uint64_t *)calloc(n, sizeof(uint64_t));
+}
+
+static void free_view(apemost_hip_state_view *v) {
+    free(v->params);
+    free(v->params_best);
+    free(v->step);
+    free(v->pmin);
+    free(v->pmax);
+    free(v->params_accepts);
+    free(v->params_rejects);
+    free(v->beta);
+    free(v->prob);
+    free(v->prior);
+    free(v->prob_best);
+    free(v->accept);
+    free(v->reject);
+    free(v->n_iter);
+    free(v->swapcount);
+    free(v->ticks);
+}
+
+void apemost_ladder_upload(apemost_ladder *l) {
+    const unsigned int np = l->n_par;
+    unsigned int c, p;
+    for (c = 0; c < l->n; c++) {
+        const mcmc *m = l->chains[c];
+        for (p = 0; p < np; p++) {
+            const size_t k = (size_t)c * np + p;
+            l->v.params[k] = gsl_vector_get(m->params, p);
+            l->v.params_best[k] = gsl_vector_get(m->params_best, p);
+            l->v.step[k] = gsl_vector_get(m->params_step, p);
+            l->v.pmin[k] = gsl_vector_get(m->params_min, p);
+            l->v.pmax[k] = gsl_vector_get(m->params_max, p);
+            l->v.params_accepts[k] = m->params_accepts[p];
+            l->v.params_rejects[k] = m->params_rejects[p];
+        }
+        l->v.beta[c] = pt(m) ? pt(m)->beta : 1.0;
+        l->v.swapcount[c] = pt(m) ? pt(m)->swapcount : 0;
+        l->v.ticks[c] = pt(m) ? pt(m)->tick : 0;
+        l->v.prob[c] = m->prob;
+        l->v.prior[c] = m->prior;
+        l->v.prob_best[c] = m->prob_best;
+        l->v.accept[c] = m->accept;
+        l->v.reject[c] = m->reject;
+        l->v.n_iter[c] = m->n_iter;
+    }
+    apemost_hip_or_die(apemost_hip_set_state(l->s, &l->v), "apemost_hip_set_state");
+}
+
+void apemost_ladder_download(apemost_ladder *l) {
+    const unsigned int np = l->n_par;
+    unsigned int c, p;
+    apemost_hip_or_die(apemost_hip_get_state(l->s, &l->v), "apemost_hip_get_state");
+    for (c = 0; c < l->n; c++) {
+        mcmc *m = l->chains[c];
+        for (p = 0; p < np; p++) {
+            const size_t k = (size_t)c * np + p;
+            gsl_vector_set(m->params, p, l->v.params[k]);
+            gsl_vector_set(m->params_best, p, l->v.params_best[k]);
+            gsl_vector_set(m->params_step, p, l->v.step[k]);
+            m->params_accepts[p] = (unsigned long)l->v.params_accepts[k];
+            m->params_rejects[p] = (unsigned long)l->v.params_rejects[k];
+        }
+        if (pt(m)) {
+            pt(m)->swapcount = (unsigned long)l->v.swapcount[c];
+            pt(m)->tick = (unsigned long)l->v.ticks[c];
+        }
+        m->prob = l->v.prob[c];
+        m->prior = l->v.prior[c];
+        m->prob_best = l->v.prob_best[c];
+        m->accept = (unsigned long)l->v.accept[c];
+        m->reject = (unsigned long)l->v.reject[c];
+        m->n_iter = (unsigned long)l->v.n_iter[c];
+    }
+}
+
+apemost_ladder *apemost_ladder_open(mcmc **chains, unsigned int n_chains) {
+    apemost_ladder *l = (apemost_ladder *)calloc(1, sizeof(apemost_ladder));
+    const int model = apemost_detect_model(chains[0]);
+    l->chains = chains;
+    l->n = n_chains;
+    l->n_par = chains[0]->n_par;
+    l->s = create_sampler(chains[0], model, n_chains, 0, n_chains);
+    alloc_view(l);
+    apemost_ladder_upload(l);
+    apemost_hip_or_die(apemost_hip_set_round(l->s, apemost_swap_round, 0), "apemost_hip_set_round");
+    return l;
+}
+
+void apemost_ladder_close(apemost_ladder *l) {
+    if (l == NULL)
+        return;
+    apemost_hip_destroy(l->s);
+    free_view(&l->v);
+    free(l);
+}
+
+apemost_hip_sampler *apemost_ladder_sampler(apemost_ladder *l) { return l->s; }
+
+/* one-chain twin for the single-chain API; rebuilt when the data matrix or n_par changes */
+#define SINGLE_LADDER_SPAN 1048576L
+apemost_ladder *apemost_single(mcmc *m) {
+    static apemost_ladder *cache = NULL;
+    static const gsl_matrix *cache_data = NULL;
+    static mcmc *slot[1];
+    if (cache == NULL || cache_data != m->data || cache->n_par != m->n_par) {
+        const int model = apemost_detect_model(m);
+        apemost_ladder_close(cache);
+        cache = (apemost_ladder *)calloc(1, sizeof(apemost_ladder));
+        cache->chains = slot;
+        cache->n = 1;
+        cache->n_par = m->n_par;
+        cache->s = create_sampler(m, model, 1, 0, SINGLE_LADDER_SPAN);
+        alloc_view(cache);
+        cache_data = m->data;
+    }
+    slot[0] = m;
+    apemost_hip_or_die(apemost_hip_set_chain_offset(cache->s, pt(m) ? (long)(pt(m)->chain_id % SINGLE_LADDER_SPAN) : 0),
+                       "apemost_hip_set_chain_offset");
+    return cache;
+}

@@ -136,6 +136,9 @@ class HipSampler:
     def launch_round(self, n_steps, apply_swap, d_samples=0):
         capi.check(self.L.apemost_hip_launch_round(self._h, n_steps, int(apply_swap), d_samples))
 
+    def markov_chain_step_for(self, param, n_steps=1, d_samples=0):
+        capi.check(self.L.apemost_hip_launch_round_for(self._h, n_steps, param, d_samples))
+
     def run_sampler(self, n_rounds, n_swap, d_samples=0):
         """n_rounds x {n_swap steps per chain, one swap attempt}; asynchronous."""
         capi.check(self.L.apemost_hip_run(self._h, n_rounds, n_swap, d_samples))

@@ -124,6 +124,8 @@ def main():
     eng = HipShardEngine(s, torch)
     ladder = ShardedLadder(eng, n_global, lo, n_local, rank, world, dist if world > 1 else None)
 
+    ladder.prime()
+
     def one_step():
         ladder.run_sampler(R, n_swap, samples)
 

@@ -140,6 +140,9 @@ int apemost_hip_synchronize(apemost_hip_sampler *s);
 /* the HIP stream (hipStream_t) every launch of this sampler goes to */
 int apemost_hip_stream(apemost_hip_sampler *s, void **stream);
 int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, int *data_in_lds);
+/* move the shard along the ladder (single-chain API of the C host layer: the chain's ladder
+ * position selects its RNG streams); offset + n_chains must stay <= n_chains_global */
+int apemost_hip_set_chain_offset(apemost_hip_sampler *s, int64_t chain_offset);
 
 /* ---- data and state (mcmc_load_data / setup_chains / read_calibration_file) */
 /* row-major [n_data][n_cols] host matrix, as gsl_matrix stores it */
@@ -172,10 +175,20 @@ int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params,
 int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap,
                              double *d_samples);
 
+/* n_steps x markov_chain_step_for(m, param) (src/markov_chain.c:317-333) for every resident
+ * chain: only parameter `param` is proposed, only its counters move */
+int apemost_hip_launch_round_for(apemost_hip_sampler *s, uint32_t n_steps, int32_t param, double *d_samples);
+
 /* run_sampler() for a ladder that lives entirely on this device: n_rounds x
  * {n_swap steps, swap attempt}; the last swap is applied before returning
  * control (still asynchronous).  d_samples: DEVICE [n_rounds*n_swap][n_chains][n_par+2] or NULL */
 int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32_t n_swap, double *d_samples);
+
+/* device buffers for sample rows, for hosts without their own device allocator (the C host
+ * layer): [n_steps][n_chains][n_par+2] doubles */
+int apemost_hip_samples_alloc(apemost_hip_sampler *s, uint64_t n_steps, double **d_samples);
+int apemost_hip_samples_read(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps, double *host);
+int apemost_hip_samples_free(apemost_hip_sampler *s, double *d_samples);
 
 /* pair index `a` that tempering_interaction() will pick at swap-stream position
  * `round` (parallel_tempering_decide_swap_now, interaction.c:87-97); -1 if n_global==1 */

@@ -36,6 +36,7 @@ def _worker(rank, world, port, n_global, n_rounds, n_swap, seed, out_dir):
     st, lad, _ = make_pair(w, hi - lo, seed=seed, chain_offset=lo, n_global=n_global)
     eng = OracleShardEngine(lad, seed, n_global, torch)
     ladder = ShardedLadder(eng, n_global, lo, hi - lo, rank, world, dist)
+    ladder.prime()
     ladder.run_sampler(n_rounds, n_swap)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), exchanges=ladder.exchanges, ticks=eng.rng.ticks,
              **{f: getattr(lad, f) for f in FIELDS})
