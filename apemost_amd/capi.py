@@ -27,7 +27,8 @@ class ApemostHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("model", C.c_int32),
                 ("n_par", C.c_int32), ("n_chains", C.c_int32), ("n_data", C.c_int32),
-                ("n_cols", C.c_int32), ("waves_per_chain", C.c_int32), ("chain_offset", C.c_int64),
+                ("n_cols", C.c_int32), ("waves_per_chain", C.c_int32), ("lds_policy", C.c_int32),
+                ("reserved", C.c_int32), ("chain_offset", C.c_int64),
                 ("n_chains_global", C.c_int64), ("seed", C.c_uint64), ("sigma", C.c_double),
                 ("hmin", C.c_double)]
 

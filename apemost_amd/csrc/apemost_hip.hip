@@ -30,13 +30,25 @@ struct RoundArgs {
     double *samples; // [n_steps][n_chains][n_par+2] or nullptr
 };
 
-template <int MODEL, int WAVES, bool LDS_DATA>
-__device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA> &e, const DevArrays &d,
+// candidate sets kept in LDS: 4-slot ring with a producer wave, WAVES without
+__host__ __device__ constexpr int cand_slots(int waves) { return waves > 4 ? waves : 4; }
+// two producer wavefronts join every multi-wave workgroup that still fits 1024 threads
+__host__ __device__ constexpr bool has_producer(int waves) { return waves > 1 && waves < 16; }
+__host__ __device__ constexpr int block_threads(int waves) { return (waves + (has_producer(waves) ? 2 : 0)) * kWave; }
+
+template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
+__device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
                                              const ChainShape &sh, int c, double *lds) {
-    constexpr int kThreads = WAVES * kWave;
-    e.tid = threadIdx.x;
+    constexpr int kThreads = (WAVES + (PRODUCER ? 2 : 0)) * kWave;
+    // Wave roles.  A workgroup's wavefronts are dealt to the CU's four SIMDs cyclically, so
+    // with producers the chain owner (role 0) is hardware wave 3 and the producers are hardware
+    // waves 1 and 2: three different SIMDs, and the owner's serial code does not share issue
+    // slots with candidate generation.
+    constexpr int kWavesInBlock = kThreads / kWave;
+    const int hw_wave = threadIdx.x / kWave;
     e.lane = threadIdx.x & (kWave - 1);
-    e.wave = threadIdx.x / kWave;
+    e.wave = hw_wave;
+    e.tid = e.wave * kWave + e.lane;
     e.n_par = sh.n_par;
     e.n_data = sh.n_data;
     e.consts = sh.consts;
@@ -46,11 +58,11 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA> &e, 
     e.s_par = lds;              // 2*64 doubles
     e.s_part = lds + 2 * kWave; // 2*16 doubles, then 8 control words
     e.s_cand = (double2 *)(lds + kFixedLdsDoubles);
-    double *s_data = lds + kFixedLdsDoubles + WAVES * 2 * kWave;
+    double *s_data = lds + kFixedLdsDoubles + cand_slots(WAVES) * 2 * kWave;
     e.setup_lanes();
     if (LDS_DATA) {
         // stage the data vector once per launch: coalesced HBM/L2 reads, SoA in LDS
-        for (int i = e.tid; i < 2 * sh.n_data; i += kThreads)
+        for (int i = threadIdx.x; i < 2 * sh.n_data; i += kThreads)
             s_data[i] = d.data[i];
         e.xs = s_data;
         e.ys = s_data + sh.n_data;
@@ -65,24 +77,24 @@ template <class E>
 __device__ __forceinline__ void chain_load(E &e, const DevArrays &d, const ChainShape &sh, int c,
                                            int cur) {
     const int row = c + 1, n = sh.n_par;
-    e.beta_all = d.beta[row];
+    e.beta_all = d.beta()[row];
     e.cur = e.best = e.stepw = e.lo = e.hi = 0;
     e.pacc = e.prej = 0;
-    e.prob = d.prob[cur][row];
-    e.prior = d.prior[cur][row];
-    e.prob_best = d.prob_best[cur][row];
-    e.accept = d.accept[c];
-    e.reject = d.reject[c];
-    e.tick = d.ticks[c];
+    e.prob = d.prob(cur)[row];
+    e.prior = d.prior(cur)[row];
+    e.prob_best = d.prob_best(cur)[row];
+    e.accept = d.accept()[c];
+    e.reject = d.reject()[c];
+    e.tick = d.ticks()[c];
     if (e.wave == 0 && e.is_cand) {
         const size_t k = (size_t)c * n + e.grp;
-        e.cur = d.params[cur][(size_t)row * n + e.grp];
-        e.best = d.params_best[cur][(size_t)row * n + e.grp];
-        e.stepw = d.step[k];
-        e.lo = d.pmin[k];
-        e.hi = d.pmax[k];
-        e.pacc = d.params_accepts[k];
-        e.prej = d.params_rejects[k];
+        e.cur = d.params(cur)[(size_t)row * n + e.grp];
+        e.best = d.params_best(cur)[(size_t)row * n + e.grp];
+        e.stepw = d.step()[k];
+        e.lo = d.pmin()[k];
+        e.hi = d.pmax()[k];
+        e.pacc = d.params_accepts()[k];
+        e.prej = d.params_rejects()[k];
     }
 }
 
@@ -94,20 +106,20 @@ __device__ __forceinline__ void chain_store(const E &e, const DevArrays &d, cons
         return;
     if (e.is_cand && e.qidx == 0) {
         const size_t k = (size_t)c * n + e.grp;
-        d.params[dst][(size_t)row * n + e.grp] = e.cur;
-        d.params_best[dst][(size_t)row * n + e.grp] = e.best;
-        d.params_accepts[k] = e.pacc;
-        d.params_rejects[k] = e.prej;
+        d.params(dst)[(size_t)row * n + e.grp] = e.cur;
+        d.params_best(dst)[(size_t)row * n + e.grp] = e.best;
+        d.params_accepts()[k] = e.pacc;
+        d.params_rejects()[k] = e.prej;
         if (store_step)
-            d.step[k] = e.stepw;
+            d.step()[k] = e.stepw;
     }
     if (e.lane == 63) {
-        d.prob[dst][row] = e.prob;
-        d.prior[dst][row] = e.prior;
-        d.prob_best[dst][row] = e.prob_best;
-        d.accept[c] = e.accept;
-        d.reject[c] = e.reject;
-        d.ticks[c] = e.tick;
+        d.prob(dst)[row] = e.prob;
+        d.prior(dst)[row] = e.prior;
+        d.prob_best(dst)[row] = e.prob_best;
+        d.accept()[c] = e.accept;
+        d.reject()[c] = e.reject;
+        d.ticks()[c] = e.tick;
     }
 }
 
@@ -133,35 +145,37 @@ __device__ __forceinline__ void swap_in(E &e, const DevArrays &d, const ChainSha
     const int row = c + 1;
     const int row_a = (g == a) ? row : row - 1, row_b = row_a + 1;
     const int partner = (g == a) ? row_b : row_a;
-    const double a_prob = d.prob[cur][row_a], b_prob = d.prob[cur][row_b];
-    const double a_beta = d.beta[row_a], b_beta = d.beta[row_b];
+    const double a_prob = d.prob(cur)[row_a], b_prob = d.prob(cur)[row_b];
+    const double a_beta = d.beta()[row_a], b_beta = d.beta()[row_b];
     const double r = a_beta * b_prob / b_beta + b_beta * a_prob / a_beta - (a_prob + b_prob);
     if (!(r > lc))
         return;
     // parallel_tempering_do_swap: params exchanged, prob is not (quirk Q1)
     if (e.is_cand)
-        e.cur = d.params[cur][(size_t)partner * n + e.grp];
-    const double a_best = d.prob_best[cur][row_a], b_best = d.prob_best[cur][row_b];
+        e.cur = d.params(cur)[(size_t)partner * n + e.grp];
+    const double a_best = d.prob_best(cur)[row_a], b_best = d.prob_best(cur)[row_b];
     const bool a_wins = a_best > b_best;
     if ((g == a) != a_wins) { // this chain receives the other one's best (quirk Q3)
         e.prob_best = a_wins ? a_best : b_best;
         if (e.is_cand)
-            e.best = d.params_best[cur][(size_t)partner * n + e.grp];
+            e.best = d.params_best(cur)[(size_t)partner * n + e.grp];
     }
     if (g == a && e.lane == 0)
-        d.swapcount[c] += 1; // inc_swapcount(chains[candidate])
+        d.swapcount()[c] += 1; // inc_swapcount(chains[candidate])
 }
 
 template <int MODEL, int WAVES, bool LDS_DATA>
-__global__ __launch_bounds__(WAVES *kWave) void pt_round_kernel(const RoundArgs a) {
+__global__ __launch_bounds__(block_threads(WAVES)) void pt_round_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
-    Engine<MODEL, WAVES, LDS_DATA> e;
+    Engine<MODEL, WAVES, LDS_DATA, has_producer(WAVES)> e;
     const int c = blockIdx.x;
     engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
     if (a.apply_swap)
         swap_in(e, a.d, a.sh, c, a.cur, a.round);
+    e.producer_prologue();
     __syncthreads();
+    e.producer_first_fetch();
 #ifdef APEMOST_STAMPS
     e.stamps_begin();
 #endif
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_round_kernel(const RoundArgs 
     e.stamps_flush();
 #endif
     if (e.wave == 0 && e.lane == 0)
-        a.d.n_iter[c] += a.n_steps; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
+        a.d.n_iter()[c] += a.n_steps; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
     chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
 }
 
@@ -202,8 +216,8 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const Round
     __syncthreads();
     e.calc_model_current();
     if (e.wave == 0 && e.lane == 0) {
-        a.d.prob[a.cur][c + 1] = e.prob;
-        a.d.prior[a.cur][c + 1] = e.prior;
+        a.d.prob(a.cur)[c + 1] = e.prob;
+        a.d.prior(a.cur)[c + 1] = e.prior;
     }
 }
 
@@ -222,6 +236,10 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_loglike_kernel(const EvalArgs
     extern __shared__ __align__(16) double lds[];
     Engine<MODEL, WAVES, LDS_DATA> e;
     DevArrays d;
+    d.f = nullptr;
+    d.u = nullptr;
+    d.n = a.sh.n_chains;
+    d.np = a.sh.n_par;
     d.data = a.data;
     const int c = blockIdx.x;
     engine_setup(e, d, a.sh, c, lds);
@@ -249,17 +267,19 @@ struct CalibArgs {
 };
 
 template <int MODEL, int WAVES, bool LDS_DATA>
-__global__ __launch_bounds__(WAVES *kWave) void pt_calibrate_kernel(const CalibArgs a) {
+__global__ __launch_bounds__(block_threads(WAVES)) void pt_calibrate_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
     // control word decided by wave 0, read by every wave (kept inside the dynamic
     // region so the carve base stays 16-byte aligned)
     volatile int &s_ctl = *(volatile int *)(lds + 2 * kWave + 32);
-    Engine<MODEL, WAVES, LDS_DATA> e;
+    Engine<MODEL, WAVES, LDS_DATA, has_producer(WAVES)> e;
     const int c = a.first + blockIdx.x;
     const int n = a.sh.n_par;
     engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
+    e.producer_prologue();
     __syncthreads();
+    e.producer_first_fetch();
     const bool w0 = (e.wave == 0);
     const apemost_hip_calib_config &cfg = a.cfg;
 
@@ -433,26 +453,26 @@ __global__ void rng_attempts_kernel(u64 seed, u64 chain, int slot, u64 tick, u64
 __global__ void edge_export_kernel(DevArrays d, int n_par, int cur, int row, double *buf) {
     const int t = threadIdx.x;
     if (t == 0) {
-        buf[0] = d.beta[row];
-        buf[1] = d.prob[cur][row];
-        buf[2] = d.prob_best[cur][row];
+        buf[0] = d.beta()[row];
+        buf[1] = d.prob(cur)[row];
+        buf[2] = d.prob_best(cur)[row];
     }
     if (t < n_par) {
-        buf[3 + t] = d.params[cur][(size_t)row * n_par + t];
-        buf[3 + n_par + t] = d.params_best[cur][(size_t)row * n_par + t];
+        buf[3 + t] = d.params(cur)[(size_t)row * n_par + t];
+        buf[3 + n_par + t] = d.params_best(cur)[(size_t)row * n_par + t];
     }
 }
 
 __global__ void edge_import_kernel(DevArrays d, int n_par, int cur, int row, const double *buf) {
     const int t = threadIdx.x;
     if (t == 0) {
-        d.beta[row] = buf[0];
-        d.prob[cur][row] = buf[1];
-        d.prob_best[cur][row] = buf[2];
+        d.beta()[row] = buf[0];
+        d.prob(cur)[row] = buf[1];
+        d.prob_best(cur)[row] = buf[2];
     }
     if (t < n_par) {
-        d.params[cur][(size_t)row * n_par + t] = buf[3 + t];
-        d.params_best[cur][(size_t)row * n_par + t] = buf[3 + n_par + t];
+        d.params(cur)[(size_t)row * n_par + t] = buf[3 + t];
+        d.params_best(cur)[(size_t)row * n_par + t] = buf[3 + n_par + t];
     }
 }
 
@@ -486,7 +506,7 @@ struct apemost_hip_sampler {
     ChainShape sh;
     int waves;
     bool lds_data;
-    size_t lds_bytes;
+    size_t lds_bytes, lds_fixed_bytes;
     int cur;
     u64 round;
     int swap_pending;
@@ -551,16 +571,25 @@ static int dev_alloc(apemost_hip_sampler *s, T **p, size_t count) {
     return APEMOST_HIP_OK;
 }
 
+// Staging pays when the staged bytes are re-read (several steps per launch) and the LDS
+// footprint still lets enough workgroups share a CU; otherwise the data vector is read through
+// L2 (it is shared by every chain, so it stays resident there).
+static bool choose_lds(const apemost_hip_config &c, size_t lds_bytes) {
+    const long long wg_per_cu = (160 * 1024) / (long long)lds_bytes;
+    const long long wanted = ((long long)c.n_chains + 255) / 256;
+    return wg_per_cu >= (wanted < 4 ? wanted : 4);
+}
+
 static int choose_waves(const apemost_hip_config &c) {
     if (c.waves_per_chain > 0)
         return c.waves_per_chain;
     // enough wavefronts to spread the chip's 1024 SIMDs over the resident chains,
-    // but never fewer than 4 data points per lane and never more than 16 waves
+    // but never fewer than 2 data points per lane and never more than 16 waves
     int by_chip = 1;
     while (by_chip < 16 && (long long)c.n_chains * by_chip * 2 <= 2048)
         by_chip *= 2;
     int by_data = 1;
-    while (by_data < 16 && c.n_data >= by_data * 2 * kWave * 4)
+    while (by_data < 16 && c.n_data >= by_data * 2 * kWave * 2)
         by_data *= 2;
     return by_chip < by_data ? by_chip : by_data;
 }
@@ -623,29 +652,21 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
         delete s;
         return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 8 or 16");
     }
-    const size_t fixed_lds = (kFixedLdsDoubles + (size_t)s->waves * 2 * kWave) * sizeof(double);
+    const size_t fixed_lds = (kFixedLdsDoubles + (size_t)cand_slots(s->waves) * 2 * kWave) * sizeof(double);
     const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
-    s->lds_data = fixed_lds + data_lds <= 160 * 1024 - 1024;
+    s->lds_data = fixed_lds + data_lds <= 160 * 1024 - 1024 && cfg->lds_policy != 2 &&
+                  (cfg->lds_policy == 1 || choose_lds(*cfg, fixed_lds + data_lds));
     s->lds_bytes = fixed_lds + (s->lds_data ? data_lds : 0);
+    s->lds_fixed_bytes = fixed_lds;
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
 
-    const size_t n = cfg->n_chains, np = cfg->n_par, rows = n + 2;
     DevArrays &d = s->d;
-    for (int h = 0; h < 2; h++) {
-        if ((rc = dev_alloc(s, &d.params[h], rows * np)) || (rc = dev_alloc(s, &d.params_best[h], rows * np)) ||
-            (rc = dev_alloc(s, &d.prob[h], rows)) || (rc = dev_alloc(s, &d.prob_best[h], rows)) ||
-            (rc = dev_alloc(s, &d.prior[h], rows)))
-            return rc;
-    }
+    d.n = cfg->n_chains;
+    d.np = cfg->n_par;
     double *data = nullptr;
-    if ((rc = dev_alloc(s, &d.beta, rows)) || (rc = dev_alloc(s, &d.step, n * np)) ||
-        (rc = dev_alloc(s, &d.pmin, n * np)) || (rc = dev_alloc(s, &d.pmax, n * np)) ||
-        (rc = dev_alloc(s, &d.params_accepts, n * np)) || (rc = dev_alloc(s, &d.params_rejects, n * np)) ||
-        (rc = dev_alloc(s, &d.accept, n)) || (rc = dev_alloc(s, &d.reject, n)) ||
-        (rc = dev_alloc(s, &d.n_iter, n)) || (rc = dev_alloc(s, &d.swapcount, n)) ||
-        (rc = dev_alloc(s, &d.ticks, n)) ||
+    if ((rc = dev_alloc(s, &d.f, d.f_count())) || (rc = dev_alloc(s, &d.u, d.u_count())) ||
         (rc = dev_alloc(s, &data, (size_t)cfg->n_cols * cfg->n_data)))
         return rc;
     d.data = data;
@@ -759,20 +780,20 @@ static int xfer_state(apemost_hip_sampler *s, const apemost_hip_state_view *v, b
     const int h = s->cur;
     DevArrays &d = s->d;
     int rc;
-    if ((rc = xfer(s, d.params[h], v->params, np, true, up)) ||
-        (rc = xfer(s, d.params_best[h], v->params_best, np, true, up)) ||
-        (rc = xfer(s, d.prob[h], v->prob, 1, true, up)) ||
-        (rc = xfer(s, d.prob_best[h], v->prob_best, 1, true, up)) ||
-        (rc = xfer(s, d.prior[h], v->prior, 1, true, up)) || (rc = xfer(s, d.beta, v->beta, 1, true, up)) ||
-        (rc = xfer(s, d.step, v->step, np, false, up)) || (rc = xfer(s, d.pmin, v->pmin, np, false, up)) ||
-        (rc = xfer(s, d.pmax, v->pmax, np, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.params_accepts, v->params_accepts, np, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.params_rejects, v->params_rejects, np, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.accept, v->accept, 1, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.reject, v->reject, 1, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.n_iter, v->n_iter, 1, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.swapcount, v->swapcount, 1, false, up)) ||
-        (rc = xfer(s, (uint64_t *)d.ticks, v->ticks, 1, false, up)))
+    if ((rc = xfer(s, d.params(h), v->params, np, true, up)) ||
+        (rc = xfer(s, d.params_best(h), v->params_best, np, true, up)) ||
+        (rc = xfer(s, d.prob(h), v->prob, 1, true, up)) ||
+        (rc = xfer(s, d.prob_best(h), v->prob_best, 1, true, up)) ||
+        (rc = xfer(s, d.prior(h), v->prior, 1, true, up)) || (rc = xfer(s, d.beta(), v->beta, 1, true, up)) ||
+        (rc = xfer(s, d.step(), v->step, np, false, up)) || (rc = xfer(s, d.pmin(), v->pmin, np, false, up)) ||
+        (rc = xfer(s, d.pmax(), v->pmax, np, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.params_accepts(), v->params_accepts, np, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.params_rejects(), v->params_rejects, np, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.accept(), v->accept, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.reject(), v->reject, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.n_iter(), v->n_iter, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.swapcount(), v->swapcount, 1, false, up)) ||
+        (rc = xfer(s, (uint64_t *)d.ticks(), v->ticks, 1, false, up)))
         return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     return APEMOST_HIP_OK;
@@ -806,9 +827,10 @@ enum KernelKind { K_ROUND, K_CALC, K_EVAL, K_CALIB };
 template <int MODEL, int WAVES, bool LDS>
 static hipError_t launch_one(KernelKind kind, int grid, size_t lds, hipStream_t st, const void *args) {
     const dim3 g(grid), b(WAVES * kWave);
+    const dim3 bp(block_threads(WAVES)); // + producer wave
     switch (kind) {
     case K_ROUND:
-        hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS>), g, b, lds, st, *(const RoundArgs *)args);
+        hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS>), g, bp, lds, st, *(const RoundArgs *)args);
         break;
     case K_CALC:
         hipLaunchKernelGGL((pt_calc_model_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
@@ -818,7 +840,7 @@ static hipError_t launch_one(KernelKind kind, int grid, size_t lds, hipStream_t 
         hipLaunchKernelGGL((pt_loglike_kernel<MODEL, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
         break;
     case K_CALIB:
-        hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
+        hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS>), g, bp, lds, st,
                            *(const CalibArgs *)args);
         break;
     }
@@ -849,20 +871,24 @@ static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, int grid, 
                     : launch_w<MODEL, false>(waves, kind, grid, lds, st, args);
 }
 
-static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args) {
+// stage_data: a launch that walks the data vector only a few times (n_swap < 4, single
+// likelihood evaluations) reads it through L2 instead of copying it into LDS first
+static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true) {
     hipError_t err;
+    const bool lds_data = s->lds_data && (stage_data || s->cfg.lds_policy == 1);
+    const size_t lds_bytes = lds_data ? s->lds_bytes : s->lds_fixed_bytes;
     switch (s->cfg.model) {
     case APEMOST_MODEL_SIMPLESIN:
-        err = launch_m<APEMOST_MODEL_SIMPLESIN>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_SIMPLESIN>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
         break;
     case APEMOST_MODEL_PULSE:
-        err = launch_m<APEMOST_MODEL_PULSE>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_PULSE>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
         break;
     case APEMOST_MODEL_PULSE_VROT:
-        err = launch_m<APEMOST_MODEL_PULSE_VROT>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_PULSE_VROT>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
         break;
     default:
-        err = launch_m<APEMOST_MODEL_SINE3>(s->lds_data, s->waves, kind, grid, s->lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_SINE3>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
         break;
     }
     if (err != hipSuccess)
@@ -889,7 +915,7 @@ extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int
     a.n_steps = 0;
     a.round = 0;
     a.samples = nullptr;
-    return launch(s, K_CALC, count, &a);
+    return launch(s, K_CALC, count, &a, false);
 }
 
 extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params,
@@ -912,7 +938,7 @@ extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const doub
     a.beta = d_beta;
     a.prob = d_prob;
     a.prior = d_prior;
-    int rc = launch(s, K_EVAL, n, &a);
+    int rc = launch(s, K_EVAL, n, &a, false);
     if (!rc) {
         HIP_TRY(hipMemcpyAsync(prob, d_prob, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         if (prior)
@@ -1015,7 +1041,7 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_steps, int apply
     a.n_steps = n_steps;
     a.round = s->round;
     a.samples = d_samples;
-    rc = launch(s, K_ROUND, s->cfg.n_chains, &a);
+    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, n_steps >= 4);
     if (rc)
         return rc;
     s->cur ^= 1;

@@ -53,6 +53,7 @@ static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned in
     cfg.n_data = (int)m->data->size1;
     cfg.n_cols = (int)m->data->size2;
     cfg.waves_per_chain = waves ? atoi(waves) : 0;
+    cfg.lds_policy = getenv("APEMOST_LDS") ? atoi(getenv("APEMOST_LDS")) : 0;
     cfg.chain_offset = chain_offset;
     cfg.n_chains_global = n_global;
     cfg.seed = env_seed();

@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--n-swap", type=int, default=0, help="0 = reference rule 2000/n_beta of the per-GPU ladder")
     ap.add_argument("--rounds-per-step", type=int, default=32)
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--lds", type=int, default=0, help="0 choose, 1 stage the data vector in LDS, 2 read it through L2")
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
     return ap.parse_args()
@@ -115,7 +116,7 @@ def main():
         st.step[i] = np.minimum(st.step[i] * b ** -0.5, w.pmax - w.pmin)
 
     s = HipSampler(w.model, w.n_par, n_local, w.data, seed=2024, device=local_rank, chain_offset=lo,
-                   n_chains_global=n_global, waves_per_chain=a.waves)
+                   n_chains_global=n_global, waves_per_chain=a.waves, lds_policy=a.lds)
     s.set_state(st)
     waves, lds = s.geometry
     samples = None
