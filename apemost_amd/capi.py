@@ -53,7 +53,8 @@ EXPORTS = [
     "apemost_hip_device_info", "apemost_hip_create", "apemost_hip_destroy", "apemost_hip_synchronize",
     "apemost_hip_stream", "apemost_hip_waves_per_chain", "apemost_hip_set_chain_offset", "apemost_hip_set_data", "apemost_hip_set_state",
     "apemost_hip_get_state", "apemost_hip_set_round", "apemost_hip_get_round", "apemost_hip_calc_model",
-    "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
+    "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_launch_rounds", "apemost_hip_max_rounds_per_launch",
+    "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
     "apemost_hip_samples_read", "apemost_hip_samples_free", "apemost_hip_swap_pair",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_rng_raw",
@@ -102,6 +103,8 @@ def lib():
     L.apemost_hip_loglike.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp]
     L.apemost_hip_launch_round.argtypes = [vp, C.c_uint32, C.c_int, vp]
     L.apemost_hip_launch_round_for.argtypes = [vp, C.c_uint32, C.c_int32, vp]
+    L.apemost_hip_launch_rounds.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp]
+    L.apemost_hip_max_rounds_per_launch.argtypes = [vp, C.POINTER(C.c_int32)]
     L.apemost_hip_run.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
     L.apemost_hip_swap_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]
     L.apemost_hip_swap_pair.restype = C.c_int64

@@ -25,7 +25,8 @@ struct RoundArgs {
     int first;        // first local chain (calc_model on a range)
     int which;        // -1: all-parameter updates; p: update parameter p only (markov_chain_step_for)
     int apply_swap;   // fuse tempering_interaction() for swap-stream position `round`
-    unsigned n_steps; // Metropolis steps in this launch
+    unsigned n_steps; // Metropolis steps per round
+    unsigned n_rounds; // rounds in this launch; between them the swap attempts are exchanged in-kernel
     u64 round;
     double *samples; // [n_steps][n_chains][n_par+2] or nullptr
 };
@@ -35,6 +36,7 @@ __host__ __device__ constexpr int cand_slots(int waves) { return waves > 4 ? wav
 // two producer wavefronts join every multi-wave workgroup that still fits 1024 threads
 __host__ __device__ constexpr bool has_producer(int waves) { return waves > 1 && waves < 16; }
 __host__ __device__ constexpr int block_threads(int waves) { return (waves + (has_producer(waves) ? 2 : 0)) * kWave; }
+static int block_threads_rt(int waves) { return block_threads(waves); }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
 __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
@@ -123,45 +125,156 @@ __device__ __forceinline__ void chain_store(const E &e, const DevArrays &d, cons
     }
 }
 
-// tempering_interaction() fused into the start of a round
-// (src/parallel_tempering_interaction.c:25-42, 87-123, 125-141).  Every
-// workgroup derives the same pair and the same uniforms from the replicated swap
-// stream; the two workgroups of the pair evaluate the same expression on the same
-// (read-only) values, so they agree without talking to each other.
+// ---- agent-scope accessors for words another workgroup of the same launch writes or reads
+// (cdna_hip_programming.md Guideline 16: global address space, sc1, never plain) ----
+typedef __attribute__((address_space(1))) u64 gu64;
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store((gu64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(u64 *p, u64 v) {
+    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_agent(const u64 *p) {
+    return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// bounded relaxed poll by one wave on one word; on timeout the launch's timeout word is set and
+// the host reports the failure (results of that launch are void)
+__device__ __forceinline__ bool wait_at_least(const u64 *word, u64 want, u64 *timeout_word) {
+    for (unsigned spins = 0; ld_agent(word) < want; spins++) {
+        __builtin_amdgcn_s_sleep(2);
+        if (spins > 8000000u) {
+            st_agent(timeout_word, 1);
+            return false;
+        }
+    }
+    return true;
+}
+
+// which neighbour's record a chain read at its latest use of each half of the state block, and for
+// which swap index: before the chain overwrites its row in that half it waits for that reader's ack
+struct SwapMemo {
+    int partner[2];
+    u64 index[2];
+};
+
+// tempering_interaction() (src/parallel_tempering_interaction.c:25-42, 87-123, 125-141) as seen
+// by one chain: every workgroup derives the same pair and uniforms from the replicated swap
+// stream; the two workgroups of the pair evaluate the same expression on the same values and
+// agree without negotiating.  Records are read from half `half` of the state block; `shared`
+// selects agent-scope loads (records published inside this launch) over plain ones (records
+// stored by the previous launch).  Returns the partner's local chain index, or -1.
 template <class E>
-__device__ __forceinline__ void swap_in(E &e, const DevArrays &d, const ChainShape &sh, int c, int cur,
-                                        u64 round) {
-    if (sh.n_global <= 1 || e.wave != 0)
-        return;
-    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, round);
+__device__ __forceinline__ int swap_apply(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
+                                          u64 swap_index, bool shared) {
+    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, swap_index);
     const double u = u32_to_uniform(b.x);
     const double lc = log(u32_to_uniform(b.y));
     const int nb = (int)sh.n_global;
     const long long a = (int)(nb * 1000 * u) % (nb - 1);
     const long long g = sh.chain_offset + c;
     if (g != a && g != a + 1)
-        return;
+        return -1;
     const int n = sh.n_par;
     const int row = c + 1;
     const int row_a = (g == a) ? row : row - 1, row_b = row_a + 1;
     const int partner = (g == a) ? row_b : row_a;
-    const double a_prob = d.prob(cur)[row_a], b_prob = d.prob(cur)[row_b];
+    // own values come from registers, the partner's from memory
+    const double p_prob = shared ? ld_agent(d.prob(half) + partner) : d.prob(half)[partner];
+    const double p_best = shared ? ld_agent(d.prob_best(half) + partner) : d.prob_best(half)[partner];
+    const double a_prob = (g == a) ? e.prob : p_prob, b_prob = (g == a) ? p_prob : e.prob;
     const double a_beta = d.beta()[row_a], b_beta = d.beta()[row_b];
     const double r = a_beta * b_prob / b_beta + b_beta * a_prob / a_beta - (a_prob + b_prob);
-    if (!(r > lc))
-        return;
-    // parallel_tempering_do_swap: params exchanged, prob is not (quirk Q1)
-    if (e.is_cand)
-        e.cur = d.params(cur)[(size_t)partner * n + e.grp];
-    const double a_best = d.prob_best(cur)[row_a], b_best = d.prob_best(cur)[row_b];
-    const bool a_wins = a_best > b_best;
-    if ((g == a) != a_wins) { // this chain receives the other one's best (quirk Q3)
-        e.prob_best = a_wins ? a_best : b_best;
-        if (e.is_cand)
-            e.best = d.params_best(cur)[(size_t)partner * n + e.grp];
+    if (r > lc) {
+        // parallel_tempering_do_swap: params exchanged, prob is not (quirk Q1)
+        const double a_best = (g == a) ? e.prob_best : p_best, b_best = (g == a) ? p_best : e.prob_best;
+        const bool a_wins = a_best > b_best;
+        const bool take_best = (g == a) != a_wins; // this chain receives the other one's best (quirk Q3)
+        if (e.is_cand) {
+            const double *pp = d.params(half) + (size_t)partner * n + e.grp;
+            const double *pb = d.params_best(half) + (size_t)partner * n + e.grp;
+            e.cur = shared ? ld_agent(pp) : *pp;
+            if (take_best)
+                e.best = shared ? ld_agent(pb) : *pb;
+        }
+        if (take_best)
+            e.prob_best = a_wins ? a_best : b_best;
+        if (g == a && e.lane == 0)
+            d.swapcount()[c] += 1; // inc_swapcount(chains[candidate])
     }
-    if (g == a && e.lane == 0)
-        d.swapcount()[c] += 1; // inc_swapcount(chains[candidate])
+    return partner - 1;
+}
+
+// a chain's row in half `half` is about to be overwritten: its latest reader must be done
+template <class E>
+__device__ __forceinline__ void wait_for_reader(const DevArrays &d, const ChainShape &sh, const SwapMemo &memo,
+                                                int half) {
+    const int p = memo.partner[half];
+    if (p >= 0 && p < sh.n_chains)
+        wait_at_least(d.acked() + p, memo.index[half] + 1, d.timeout_word());
+}
+
+// swap attempt at the start of a launch: both records were stored by the previous launch (or
+// imported into a halo row by the host)
+template <class E>
+__device__ __forceinline__ void swap_at_launch_start(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
+                                                     u64 swap_index, SwapMemo &memo) {
+    if (sh.n_global <= 1 || e.wave != 0)
+        return;
+    const int partner = swap_apply(e, d, sh, c, half, swap_index, false);
+    if (partner == -1)
+        return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the reads above have landed
+    if (e.lane == 0)
+        st_agent(d.acked() + c, swap_index + 1);
+    memo.partner[half] = partner;
+    memo.index[half] = swap_index;
+}
+
+// swap attempt between two rounds of one launch: the two chains of the pair publish their
+// records into half `half`, wait for each other, then decide (Guideline 16: payload and flag
+// are agent-scope sc1 stores drained by the storing wave; the consumer polls the flag relaxed,
+// takes one agent acquire, and reads the payload with agent-scope loads)
+template <class E>
+__device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
+                                               u64 swap_index, SwapMemo &memo) {
+    if (sh.n_global <= 1 || e.wave != 0)
+        return;
+    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, swap_index);
+    const int nb = (int)sh.n_global;
+    const long long a = (int)(nb * 1000 * u32_to_uniform(b.x)) % (nb - 1);
+    const long long g = sh.chain_offset + c;
+    if (g != a && g != a + 1)
+        return;
+    const int partner = (g == a) ? c + 1 : c - 1;
+    if (partner < 0 || partner >= sh.n_chains) {
+        st_agent(d.timeout_word(), 2); // the host must not schedule a shard-straddling pair in-launch
+        return;
+    }
+    const int n = sh.n_par, row = c + 1;
+    wait_for_reader<E>(d, sh, memo, half);
+    if (e.is_cand && e.qidx == 0) {
+        st_agent(d.params(half) + (size_t)row * n + e.grp, e.cur);
+        st_agent(d.params_best(half) + (size_t)row * n + e.grp, e.best);
+    }
+    if (e.lane == 63) {
+        st_agent(d.prob(half) + row, e.prob);
+        st_agent(d.prob_best(half) + row, e.prob_best);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every payload store of this wave has left
+    if (e.lane == 0)
+        st_agent(d.published() + c, swap_index + 1);
+    if (!wait_at_least(d.published() + partner, swap_index + 1, d.timeout_word()))
+        return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    swap_apply(e, d, sh, c, half, swap_index, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (e.lane == 0)
+        st_agent(d.acked() + c, swap_index + 1);
+    memo.partner[half] = partner;
+    memo.index[half] = swap_index;
 }
 
 template <int MODEL, int WAVES, bool LDS_DATA>
@@ -171,8 +284,11 @@ __global__ __launch_bounds__(block_threads(WAVES)) void pt_round_kernel(const Ro
     const int c = blockIdx.x;
     engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
+    SwapMemo memo;
+    memo.partner[0] = memo.partner[1] = -1;
+    memo.index[0] = memo.index[1] = 0;
     if (a.apply_swap)
-        swap_in(e, a.d, a.sh, c, a.cur, a.round);
+        swap_at_launch_start(e, a.d, a.sh, c, a.cur, a.round, memo);
     e.producer_prologue();
     __syncthreads();
     e.producer_first_fetch();
@@ -181,18 +297,22 @@ __global__ __launch_bounds__(block_threads(WAVES)) void pt_round_kernel(const Ro
 #endif
 
     const int n = a.sh.n_par;
-    for (unsigned s = 0; s < a.n_steps; s++) {
-        e.step(a.which);
-        if (e.wave == 0) {
-            e.check_best();
-            if (a.samples) {
-                // the row the reference prints per step: params ("%.15e"), prob, prob-prior
-                double *row = a.samples + ((size_t)s * a.sh.n_chains + c) * (n + 2);
-                if (e.is_cand && e.qidx == 0)
-                    row[e.grp] = e.cur;
-                if (e.lane == 63) {
-                    row[n] = e.prob;
-                    row[n + 1] = e.prob - e.prior;
+    for (unsigned r = 0; r < a.n_rounds; r++) {
+        if (r > 0) // the swap attempt between round r-1 and round r
+            swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
+        for (unsigned s = 0; s < a.n_steps; s++) {
+            e.step(a.which);
+            if (e.wave == 0) {
+                e.check_best();
+                if (a.samples) {
+                    // the row the reference prints per step: params ("%.15e"), prob, prob-prior
+                    double *row = a.samples + (((size_t)r * a.n_steps + s) * a.sh.n_chains + c) * (n + 2);
+                    if (e.is_cand && e.qidx == 0)
+                        row[e.grp] = e.cur;
+                    if (e.lane == 63) {
+                        row[n] = e.prob;
+                        row[n + 1] = e.prob - e.prior;
+                    }
                 }
             }
         }
@@ -201,7 +321,9 @@ __global__ __launch_bounds__(block_threads(WAVES)) void pt_round_kernel(const Ro
     e.stamps_flush();
 #endif
     if (e.wave == 0 && e.lane == 0)
-        a.d.n_iter()[c] += a.n_steps; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
+        a.d.n_iter()[c] += (u64)a.n_steps * a.n_rounds; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
+    if (e.wave == 0)
+        wait_for_reader<decltype(e)>(a.d, a.sh, memo, a.cur ^ 1);
     chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
 }
 
@@ -507,6 +629,7 @@ struct apemost_hip_sampler {
     int waves;
     bool lds_data;
     size_t lds_bytes, lds_fixed_bytes;
+    bool resident_ok; // the whole grid of the round kernel fits the device at once
     int cur;
     u64 round;
     int swap_pending;
@@ -682,6 +805,24 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     HIP_TRY(hipStreamSynchronize(s->stream));
     if ((rc = enable_big_lds(s)))
         return rc;
+    {
+        // workgroups per CU by threads (2048), wavefronts (32) and LDS (160 KiB), one held back
+        // (the occupancy query over-reports by one block for scalar-register-heavy kernels,
+        // MI355X_MICROARCH.md "Residency"), times the CU count, times a 2x margin
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+        const long long threads = block_threads_rt(s->waves);
+        long long per_cu = 2048 / threads;
+        const long long by_lds = (160 * 1024) / (long long)(s->lds_bytes > 0 ? s->lds_bytes : 1);
+        if (by_lds < per_cu)
+            per_cu = by_lds;
+        if (per_cu > 8)
+            per_cu = 8;
+        per_cu -= 1;
+        s->resident_ok = per_cu >= 1 && (long long)cfg->n_chains * 2 <= per_cu * prop.multiProcessorCount;
+        if (cfg->n_chains <= prop.multiProcessorCount / 2 && threads <= 1024 && s->lds_bytes <= 80 * 1024)
+            s->resident_ok = true; // at most one workgroup per two CUs
+    }
     *out = s;
     return APEMOST_HIP_OK;
 }
@@ -711,10 +852,21 @@ extern "C" int apemost_hip_destroy(apemost_hip_sampler *s) {
         HIP_TRY(hipSetDevice((s)->cfg.device));                                                  \
     } while (0)
 
+// in-launch swap hand-offs spin with a bound; a hit is reported here
+static int check_handoff(apemost_hip_sampler *s) {
+    u64 word = 0;
+    HIP_TRY(hipMemcpyAsync(&word, s->d.timeout_word(), sizeof word, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (word != 0)
+        return fail(APEMOST_HIP_ERR_RUNTIME, "in-launch swap hand-off failed (code %llu): the results of that launch are void",
+                    (unsigned long long)word);
+    return APEMOST_HIP_OK;
+}
+
 extern "C" int apemost_hip_synchronize(apemost_hip_sampler *s) {
     CHECK_S(s);
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return APEMOST_HIP_OK;
+    return check_handoff(s);
 }
 
 extern "C" int apemost_hip_stream(apemost_hip_sampler *s, void **stream) {
@@ -803,13 +955,17 @@ extern "C" int apemost_hip_set_state(apemost_hip_sampler *s, const apemost_hip_s
     return xfer_state(s, v, true);
 }
 extern "C" int apemost_hip_get_state(apemost_hip_sampler *s, const apemost_hip_state_view *v) {
-    return xfer_state(s, v, false);
+    int rc = xfer_state(s, v, false);
+    return rc ? rc : check_handoff(s);
 }
 
 extern "C" int apemost_hip_set_round(apemost_hip_sampler *s, uint64_t round, int swap_pending) {
     CHECK_S(s);
     s->round = round;
     s->swap_pending = swap_pending ? 1 : 0;
+    // hand-off words count swap indices upwards; a rewound swap stream restarts them
+    HIP_TRY(hipMemsetAsync(s->d.published(), 0, (2 * (size_t)s->cfg.n_chains + 2) * sizeof(u64), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return APEMOST_HIP_OK;
 }
 extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, int *swap_pending) {
@@ -913,6 +1069,7 @@ extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int
     a.which = -1;
     a.apply_swap = 0;
     a.n_steps = 0;
+    a.n_rounds = 0;
     a.round = 0;
     a.samples = nullptr;
     return launch(s, K_CALC, count, &a, false);
@@ -1012,25 +1169,51 @@ static int enable_big_lds(apemost_hip_sampler *s) {
     return APEMOST_HIP_OK;
 }
 
-static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap, int which,
+static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t n_steps, int apply_swap, int which,
                              double *d_samples);
 
 extern "C" int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap,
                                         double *d_samples) {
-    return launch_round_impl(s, n_steps, apply_swap, -1, d_samples);
+    return launch_round_impl(s, 1, n_steps, apply_swap, -1, d_samples);
+}
+
+extern "C" int apemost_hip_launch_rounds(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t n_steps,
+                                         int apply_swap, double *d_samples) {
+    if (n_rounds < 1)
+        return fail(APEMOST_HIP_ERR_INVALID, "launch_rounds: n_rounds must be >= 1");
+    return launch_round_impl(s, n_rounds, n_steps, apply_swap, -1, d_samples);
 }
 
 extern "C" int apemost_hip_launch_round_for(apemost_hip_sampler *s, uint32_t n_steps, int32_t param,
                                             double *d_samples) {
     if (s && (param < 0 || param >= s->cfg.n_par))
         return fail(APEMOST_HIP_ERR_INVALID, "launch_round_for: parameter %d outside [0,%d)", param, s->cfg.n_par);
-    return launch_round_impl(s, n_steps, 0, param, d_samples);
+    return launch_round_impl(s, 1, n_steps, 0, param, d_samples);
 }
 
-static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap, int which,
+// Multi-round launches hand swap records from workgroup to workgroup inside the launch, which
+// is only safe when every workgroup of the grid is resident at once.
+static int max_rounds_per_launch(apemost_hip_sampler *s) {
+    return s->resident_ok ? 64 : 1;
+}
+
+extern "C" int apemost_hip_max_rounds_per_launch(apemost_hip_sampler *s, int32_t *max_rounds) {
+    CHECK_S(s);
+    if (!max_rounds)
+        return fail(APEMOST_HIP_ERR_INVALID, "max_rounds is NULL");
+    *max_rounds = max_rounds_per_launch(s);
+    return APEMOST_HIP_OK;
+}
+
+static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t n_steps, int apply_swap, int which,
                              double *d_samples) {
     CHECK_S(s);
     int rc;
+    if ((int)n_rounds > max_rounds_per_launch(s))
+        return fail(APEMOST_HIP_ERR_INVALID, "%u rounds in one launch, this sampler allows %d (grid residency)",
+                    n_rounds, max_rounds_per_launch(s));
+    if (n_rounds > 1 && n_steps == 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "multi-round launches need n_steps > 0");
     RoundArgs a;
     a.d = s->d;
     a.sh = s->sh;
@@ -1039,17 +1222,17 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_steps, int apply
     a.which = which;
     a.apply_swap = apply_swap ? 1 : 0;
     a.n_steps = n_steps;
+    a.n_rounds = n_rounds;
     a.round = s->round;
     a.samples = d_samples;
-    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, n_steps >= 4);
+    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, (u64)n_steps * n_rounds >= 4);
     if (rc)
         return rc;
     s->cur ^= 1;
     s->launches++;
-    if (apply_swap) {
-        s->round++;
+    s->round += (apply_swap ? 1 : 0) + (n_rounds - 1); // swap attempts consumed by this launch
+    if (apply_swap)
         s->swap_pending = 0;
-    }
     if (n_steps > 0 && which < 0)
         s->swap_pending = 1;
     return APEMOST_HIP_OK;
@@ -1061,13 +1244,16 @@ extern "C" int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32
     if (s->cfg.n_chains != s->cfg.n_chains_global)
         return fail(APEMOST_HIP_ERR_INVALID,
                     "apemost_hip_run needs the whole ladder on one device; sharded ladders drive "
-                    "apemost_hip_launch_round + apemost_hip_edge_*");
+                    "apemost_hip_launch_rounds + apemost_hip_edge_*");
     const size_t row = (size_t)s->cfg.n_chains * (s->cfg.n_par + 2);
-    for (uint64_t r = 0; r < n_rounds; r++) {
-        int rc = apemost_hip_launch_round(s, n_swap, s->swap_pending,
-                                          d_samples ? d_samples + r * n_swap * row : nullptr);
+    const uint64_t per_launch = n_swap > 0 ? (uint64_t)max_rounds_per_launch(s) : 1;
+    for (uint64_t r = 0; r < n_rounds;) {
+        const uint64_t k = n_rounds - r < per_launch ? n_rounds - r : per_launch;
+        int rc = launch_round_impl(s, (uint32_t)k, n_swap, s->swap_pending, -1,
+                                   d_samples ? d_samples + r * n_swap * row : nullptr);
         if (rc)
             return rc;
+        r += k;
     }
     if (s->swap_pending)
         return apemost_hip_launch_round(s, 0, 1, nullptr);

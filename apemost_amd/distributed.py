@@ -19,7 +19,9 @@ def shard_bounds(n_global, world, rank):
 
 class ShardedLadder:
     """Drives one shard engine.  The engine provides
-         launch_round(n_steps, apply_swap, samples)  -- steps + fused swap-in on the local shard
+         launch_rounds(n_rounds, n_steps, apply_swap, samples) -- rounds of steps with the swaps
+                                                      between them, all inside the local shard
+         max_rounds_per_launch()
          edge_export(side) -> tensor, edge_import(side, tensor)
          swap_pair(round) -> a,  comm_stream() context manager
        `HipShardEngine` below is the product engine; the gloo tests plug in an oracle-backed one."""
@@ -68,21 +70,37 @@ class ShardedLadder:
                                                    dist.P2POp(dist.irecv, recv, peer)]):
                     req.wait()
 
-    def launch_round(self, n_steps, samples=None):
+    def _straddles(self, swap_index):
+        a = self.e.swap_pair(swap_index)
+        return a >= 0 and (a == self.lo - 1 or (a == self.hi - 1 and a + 1 < self.n_global))
+
+    def launch_rounds(self, n_rounds, n_steps, samples=None):
+        """one engine launch: [pending swap] steps [swap] steps ...; the caller guarantees that the
+        n_rounds-1 swaps inside the launch stay within this shard"""
         if self.swap_pending:
             self._exchange_if_edge()
-        self.e.launch_round(n_steps, self.swap_pending, samples)
-        if self.swap_pending:
-            self.round += 1
+        self.e.launch_rounds(n_rounds, n_steps, self.swap_pending, samples)
+        self.round += (1 if self.swap_pending else 0) + (n_rounds - 1)
         self.swap_pending = n_steps > 0
 
+    def launch_round(self, n_steps, samples=None):
+        self.launch_rounds(1, n_steps, samples)
+
     def run_sampler(self, n_rounds, n_swap, samples=None):
-        """run_sampler (src/parallel_tempering.c:392-409) on this shard; samples[r] is the
-        per-round sample block or None"""
-        for r in range(n_rounds):
-            self.launch_round(n_swap, None if samples is None else samples[r])
+        """run_sampler (src/parallel_tempering.c:392-409) on this shard.  samples: array/tensor
+        [n_rounds][n_swap][n_local][n_par+2] or None.  Rounds are batched into one engine launch
+        up to the next swap attempt that needs a neighbour's record."""
+        limit = self.e.max_rounds_per_launch()
+        r = 0
+        while r < n_rounds:
+            first_inside = self.round + (1 if self.swap_pending else 0)  # swap index after the launch's 1st round
+            k = 1
+            while k < min(limit, n_rounds - r) and not self._straddles(first_inside + k - 1):
+                k += 1
+            self.launch_rounds(k, n_swap, None if samples is None else samples[r:r + k])
+            r += k
         if self.swap_pending:
-            self.launch_round(0)
+            self.launch_rounds(1, 0)
 
 
 class HipShardEngine:
@@ -110,5 +128,8 @@ class HipShardEngine:
         self.s.edge_import(side, buf.data_ptr())
         self._keep = buf   # keep alive until the next launch consumed it
 
-    def launch_round(self, n_steps, apply_swap, samples):
-        self.s.launch_round(n_steps, apply_swap, 0 if samples is None else samples.data_ptr())
+    def max_rounds_per_launch(self):
+        return self.s.max_rounds_per_launch
+
+    def launch_rounds(self, n_rounds, n_steps, apply_swap, samples):
+        self.s.launch_rounds(n_rounds, n_steps, apply_swap, 0 if samples is None else samples.data_ptr())

@@ -136,6 +136,15 @@ class HipSampler:
     def launch_round(self, n_steps, apply_swap, d_samples=0):
         capi.check(self.L.apemost_hip_launch_round(self._h, n_steps, int(apply_swap), d_samples))
 
+    def launch_rounds(self, n_rounds, n_steps, apply_swap, d_samples=0):
+        capi.check(self.L.apemost_hip_launch_rounds(self._h, n_rounds, n_steps, int(apply_swap), d_samples))
+
+    @property
+    def max_rounds_per_launch(self):
+        v = C.c_int32(0)
+        capi.check(self.L.apemost_hip_max_rounds_per_launch(self._h, C.byref(v)))
+        return v.value
+
     def markov_chain_step_for(self, param, n_steps=1, d_samples=0):
         capi.check(self.L.apemost_hip_launch_round_for(self._h, n_steps, param, d_samples))
 

@@ -177,6 +177,15 @@ int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params,
 int apemost_hip_launch_round(apemost_hip_sampler *s, uint32_t n_steps, int apply_swap,
                              double *d_samples);
 
+/* Several rounds in one launch: [pending swap] steps [swap] steps ... (n_rounds x n_steps steps,
+ * n_rounds-1 swap attempts exchanged between workgroups inside the launch).  d_samples:
+ * DEVICE [n_rounds*n_steps][n_chains][n_par+2] or NULL.  n_rounds may not exceed
+ * apemost_hip_max_rounds_per_launch() (1 when the grid cannot be fully resident), and on a sharded
+ * ladder none of the in-launch swap attempts may pick a pair that straddles a shard edge. */
+int apemost_hip_launch_rounds(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t n_steps, int apply_swap,
+                              double *d_samples);
+int apemost_hip_max_rounds_per_launch(apemost_hip_sampler *s, int32_t *max_rounds);
+
 /* n_steps x markov_chain_step_for(m, param) (src/markov_chain.c:317-333) for every resident
  * chain: only parameter `param` is proposed, only its counters move */
 int apemost_hip_launch_round_for(apemost_hip_sampler *s, uint32_t n_steps, int32_t param, double *d_samples);

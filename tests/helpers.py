@@ -83,11 +83,18 @@ class OracleShardEngine:
     def edge_import(self, side, buf):
         self.halo[side] = buf.numpy().copy()
 
-    def launch_round(self, n_steps, apply_swap, samples):
-        if apply_swap:
-            orc.tempering_interaction_shard(self.lad, self.rng, self.n_global, self.halo[0], self.halo[1])
-            self.halo = {0: None, 1: None}
-        if n_steps:
-            out = orc.run_steps(self.lad, self.rng, n_steps, record=samples is not None)
-            if samples is not None:
-                samples[...] = self.torch.from_numpy(out)
+    def max_rounds_per_launch(self):
+        return 5
+
+    def launch_rounds(self, n_rounds, n_steps, apply_swap, samples):
+        for j in range(n_rounds):
+            if apply_swap or j > 0:
+                # swaps inside a launch never involve a halo (the driver guarantees it)
+                halos = (self.halo[0], self.halo[1]) if j == 0 else (None, None)
+                orc.tempering_interaction_shard(self.lad, self.rng, self.n_global, *halos)
+                if j == 0:
+                    self.halo = {0: None, 1: None}
+            if n_steps:
+                out = orc.run_steps(self.lad, self.rng, n_steps, record=samples is not None)
+                if samples is not None:
+                    samples[j][...] = self.torch.from_numpy(out)

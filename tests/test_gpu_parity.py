@@ -240,7 +240,7 @@ def test_two_device_shards_equal_whole_ladder(split):
                 exchanges += 1
             rnd += 1
         for e in shards:
-            e.launch_round(n_steps, pending, None)
+            e.launch_rounds(1, n_steps, pending, None)
         pending = n_steps > 0
     got = [e.s.get_state() for e in shards]
     for e in shards:
@@ -250,3 +250,26 @@ def test_two_device_shards_equal_whole_ladder(split):
               "n_iter"):
         assert np.array_equal(np.concatenate([getattr(g, f) for g in got]), getattr(ref, f)), f
     assert ref.swapcount.sum() > 0
+
+
+def test_sharded_driver_on_one_gpu_batches_rounds_and_matches_oracle():
+    """ShardedLadder (world 1) batches rounds into multi-round launches; the in-launch swap hand-off
+    between workgroups must reproduce the oracle's swaps exactly"""
+    torch = _torch()
+    from apemost_amd.distributed import HipShardEngine, ShardedLadder
+    w = wl.simplesin(n_data=128, n_chain=32)
+    n_rounds, n_swap, seed = 150, 4, 77
+    st, lad, rng = make_pair(w, 32, seed=seed)
+    s = HipSampler(w.model, 4, 32, w.data, seed=seed)
+    s.set_state(st)
+    assert s.max_rounds_per_launch > 1
+    d = torch.zeros((n_rounds, n_swap, 32, 6), dtype=torch.float64, device="cuda")
+    ladder = ShardedLadder(HipShardEngine(s, torch), 32, 0, 32, 0, 1, None)
+    ladder.run_sampler(n_rounds, n_swap, d)
+    s.synchronize()
+    dev = s.get_state()
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    assert_match(dev, lad, rng, what="batched rounds")
+    np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+    assert dev.swapcount.sum() > 10
+    s.close()
