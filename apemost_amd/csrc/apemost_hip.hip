@@ -34,9 +34,9 @@ struct RoundArgs {
 // candidate sets kept in LDS: 4-slot ring with a producer wave, WAVES without
 __host__ __device__ constexpr int cand_slots(int waves) { return waves > 4 ? waves : 4; }
 // two producer wavefronts join every multi-wave workgroup that still fits 1024 threads
+// (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
 __host__ __device__ constexpr bool has_producer(int waves) { return waves > 1 && waves < 16; }
-__host__ __device__ constexpr int block_threads(int waves) { return (waves + (has_producer(waves) ? 2 : 0)) * kWave; }
-static int block_threads_rt(int waves) { return block_threads(waves); }
+__host__ __device__ constexpr int block_threads(int waves, bool producers) { return (waves + (producers ? 2 : 0)) * kWave; }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
 __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
@@ -277,10 +277,10 @@ __device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const C
     memo.index[half] = swap_index;
 }
 
-template <int MODEL, int WAVES, bool LDS_DATA>
-__global__ __launch_bounds__(block_threads(WAVES)) void pt_round_kernel(const RoundArgs a) {
+template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
+__global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
-    Engine<MODEL, WAVES, LDS_DATA, has_producer(WAVES)> e;
+    Engine<MODEL, WAVES, LDS_DATA, PROD> e;
     const int c = blockIdx.x;
     engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
@@ -388,13 +388,13 @@ struct CalibArgs {
     u64 *iters;       // [count]
 };
 
-template <int MODEL, int WAVES, bool LDS_DATA>
-__global__ __launch_bounds__(block_threads(WAVES)) void pt_calibrate_kernel(const CalibArgs a) {
+template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
+__global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
     // control word decided by wave 0, read by every wave (kept inside the dynamic
     // region so the carve base stays 16-byte aligned)
     volatile int &s_ctl = *(volatile int *)(lds + 2 * kWave + 32);
-    Engine<MODEL, WAVES, LDS_DATA, has_producer(WAVES)> e;
+    Engine<MODEL, WAVES, LDS_DATA, PROD> e;
     const int c = a.first + blockIdx.x;
     const int n = a.sh.n_par;
     engine_setup(e, a.d, a.sh, c, lds);
@@ -627,9 +627,11 @@ struct apemost_hip_sampler {
     DevArrays d;
     ChainShape sh;
     int waves;
+    bool producers; // candidate-producer wavefronts in the round / calibrate kernels
     bool lds_data;
     size_t lds_bytes, lds_fixed_bytes;
-    bool resident_ok; // the whole grid of the round kernel fits the device at once
+    bool resident_ok; // the whole grid of the round kernel fits the device at once ...
+    bool resident_lds, resident_plain; // ... with / without the data vector staged in LDS
     int cur;
     u64 round;
     int swap_pending;
@@ -683,6 +685,8 @@ extern "C" int apemost_hip_device_info(int device, char *name, size_t name_len, 
 }
 
 static int enable_big_lds(apemost_hip_sampler *s);
+template <bool LDS>
+static hipError_t round_occupancy(int model, int waves, bool producers, size_t lds_bytes, int *blocks);
 
 template <class T>
 static int dev_alloc(apemost_hip_sampler *s, T **p, size_t count) {
@@ -714,7 +718,10 @@ static int choose_waves(const apemost_hip_config &c) {
     int by_data = 1;
     while (by_data < 16 && c.n_data >= by_data * 2 * kWave * 2)
         by_data *= 2;
-    return by_chip < by_data ? by_chip : by_data;
+    int w = by_chip < by_data ? by_chip : by_data;
+    // very long data vectors: a few waves per chain even on a full chip (shorter steps, same work)
+    const int by_length = c.n_data >= 4 * 16384 ? 4 : (c.n_data >= 2 * 16384 ? 2 : 1);
+    return w > by_length ? w : by_length;
 }
 
 extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sampler **out) {
@@ -771,6 +778,9 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->d_iters = nullptr;
     s->calib_capacity = 0;
     s->waves = choose_waves(*cfg);
+    // producer wavefronts pay while CUs are idle anyway (few chains); beyond one workgroup per
+    // CU they only take wave slots from other chains
+    s->producers = has_producer(s->waves) && cfg->n_chains <= 256;
     if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 8 && s->waves != 16) {
         delete s;
         return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 8 or 16");
@@ -806,22 +816,23 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     if ((rc = enable_big_lds(s)))
         return rc;
     {
-        // workgroups per CU by threads (2048), wavefronts (32) and LDS (160 KiB), one held back
-        // (the occupancy query over-reports by one block for scalar-register-heavy kernels,
-        // MI355X_MICROARCH.md "Residency"), times the CU count, times a 2x margin
+        // Multi-round launches need every workgroup resident at once.  Blocks per CU from the
+        // occupancy query, one held back (the query over-reports by one block for scalar-register-
+        // heavy kernels: MI355X_MICROARCH.md "Residency and cooperative launch").
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
-        const long long threads = block_threads_rt(s->waves);
-        long long per_cu = 2048 / threads;
-        const long long by_lds = (160 * 1024) / (long long)(s->lds_bytes > 0 ? s->lds_bytes : 1);
-        if (by_lds < per_cu)
-            per_cu = by_lds;
-        if (per_cu > 8)
-            per_cu = 8;
-        per_cu -= 1;
-        s->resident_ok = per_cu >= 1 && (long long)cfg->n_chains * 2 <= per_cu * prop.multiProcessorCount;
-        if (cfg->n_chains <= prop.multiProcessorCount / 2 && threads <= 1024 && s->lds_bytes <= 80 * 1024)
-            s->resident_ok = true; // at most one workgroup per two CUs
+        int b_lds = 0, b_plain = 0;
+        if (s->lds_data)
+            HIP_TRY(round_occupancy<true>(cfg->model, s->waves, s->producers, s->lds_bytes, &b_lds));
+        HIP_TRY(round_occupancy<false>(cfg->model, s->waves, s->producers, s->lds_fixed_bytes, &b_plain));
+        const long long cus = prop.multiProcessorCount;
+        s->resident_lds = s->lds_data && (long long)cfg->n_chains <= (long long)(b_lds - 1) * cus;
+        s->resident_plain = (long long)cfg->n_chains <= (long long)(b_plain - 1) * cus;
+        if ((long long)cfg->n_chains * 2 <= cus) { // at most one workgroup per two CUs
+            s->resident_lds = s->lds_data;
+            s->resident_plain = true;
+        }
+        s->resident_ok = s->resident_lds || s->resident_plain;
     }
     *out = s;
     return APEMOST_HIP_OK;
@@ -981,12 +992,16 @@ extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, in
 enum KernelKind { K_ROUND, K_CALC, K_EVAL, K_CALIB };
 
 template <int MODEL, int WAVES, bool LDS>
-static hipError_t launch_one(KernelKind kind, int grid, size_t lds, hipStream_t st, const void *args) {
+static hipError_t launch_one(KernelKind kind, bool producers, int grid, size_t lds, hipStream_t st, const void *args) {
     const dim3 g(grid), b(WAVES * kWave);
-    const dim3 bp(block_threads(WAVES)); // + producer wave
+    constexpr bool kCanProduce = has_producer(WAVES);
+    const dim3 bp(block_threads(WAVES, kCanProduce)); // + producer waves
     switch (kind) {
     case K_ROUND:
-        hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS>), g, bp, lds, st, *(const RoundArgs *)args);
+        if (kCanProduce && producers)
+            hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
+        else
+            hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, false>), g, b, lds, st, *(const RoundArgs *)args);
         break;
     case K_CALC:
         hipLaunchKernelGGL((pt_calc_model_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
@@ -996,55 +1011,59 @@ static hipError_t launch_one(KernelKind kind, int grid, size_t lds, hipStream_t 
         hipLaunchKernelGGL((pt_loglike_kernel<MODEL, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
         break;
     case K_CALIB:
-        hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS>), g, bp, lds, st,
-                           *(const CalibArgs *)args);
+        if (kCanProduce && producers)
+            hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st,
+                               *(const CalibArgs *)args);
+        else
+            hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, false>), g, b, lds, st,
+                               *(const CalibArgs *)args);
         break;
     }
     return hipGetLastError();
 }
 
 template <int MODEL, bool LDS>
-static hipError_t launch_w(int waves, KernelKind kind, int grid, size_t lds, hipStream_t st,
+static hipError_t launch_w(int waves, KernelKind kind, bool producers, int grid, size_t lds, hipStream_t st,
                            const void *args) {
     switch (waves) {
     case 1:
-        return launch_one<MODEL, 1, LDS>(kind, grid, lds, st, args);
+        return launch_one<MODEL, 1, LDS>(kind, producers, grid, lds, st, args);
     case 2:
-        return launch_one<MODEL, 2, LDS>(kind, grid, lds, st, args);
+        return launch_one<MODEL, 2, LDS>(kind, producers, grid, lds, st, args);
     case 4:
-        return launch_one<MODEL, 4, LDS>(kind, grid, lds, st, args);
+        return launch_one<MODEL, 4, LDS>(kind, producers, grid, lds, st, args);
     case 8:
-        return launch_one<MODEL, 8, LDS>(kind, grid, lds, st, args);
+        return launch_one<MODEL, 8, LDS>(kind, producers, grid, lds, st, args);
     default:
-        return launch_one<MODEL, 16, LDS>(kind, grid, lds, st, args);
+        return launch_one<MODEL, 16, LDS>(kind, producers, grid, lds, st, args);
     }
 }
 
 template <int MODEL>
-static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, int grid, size_t lds, hipStream_t st,
-                           const void *args) {
-    return lds_data ? launch_w<MODEL, true>(waves, kind, grid, lds, st, args)
-                    : launch_w<MODEL, false>(waves, kind, grid, lds, st, args);
+static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, bool producers, int grid, size_t lds,
+                           hipStream_t st, const void *args) {
+    return lds_data ? launch_w<MODEL, true>(waves, kind, producers, grid, lds, st, args)
+                    : launch_w<MODEL, false>(waves, kind, producers, grid, lds, st, args);
 }
 
 // stage_data: a launch that walks the data vector only a few times (n_swap < 4, single
 // likelihood evaluations) reads it through L2 instead of copying it into LDS first
 static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true) {
     hipError_t err;
-    const bool lds_data = s->lds_data && (stage_data || s->cfg.lds_policy == 1);
+    const bool lds_data = s->lds_data && stage_data;
     const size_t lds_bytes = lds_data ? s->lds_bytes : s->lds_fixed_bytes;
     switch (s->cfg.model) {
     case APEMOST_MODEL_SIMPLESIN:
-        err = launch_m<APEMOST_MODEL_SIMPLESIN>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_SIMPLESIN>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
         break;
     case APEMOST_MODEL_PULSE:
-        err = launch_m<APEMOST_MODEL_PULSE>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_PULSE>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
         break;
     case APEMOST_MODEL_PULSE_VROT:
-        err = launch_m<APEMOST_MODEL_PULSE_VROT>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_PULSE_VROT>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
         break;
     default:
-        err = launch_m<APEMOST_MODEL_SINE3>(lds_data, s->waves, kind, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_SINE3>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
         break;
     }
     if (err != hipSuccess)
@@ -1113,7 +1132,15 @@ extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const doub
 template <int MODEL, int WAVES>
 static hipError_t set_lds_attr(size_t bytes) {
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true>,
+    e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return e;
+    e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true, has_producer(WAVES)>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return e;
+    e = hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true, has_producer(WAVES)>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
         return e;
@@ -1125,7 +1152,7 @@ static hipError_t set_lds_attr(size_t bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
         return e;
-    return hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true>,
+    return hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
@@ -1142,6 +1169,40 @@ static hipError_t set_lds_attr_w(int waves, size_t bytes) {
         return set_lds_attr<MODEL, 8>(bytes);
     default:
         return set_lds_attr<MODEL, 16>(bytes);
+    }
+}
+
+// blocks of the round kernel one CU admits (occupancy API: registers, LDS, wave slots)
+template <int MODEL, bool LDS>
+static hipError_t round_occupancy_w(int waves, bool producers, size_t lds_bytes, int *blocks) {
+    switch (waves) {
+    case 1:
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 1, LDS, false>, block_threads(1, false), lds_bytes);
+    case 2:
+        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 2, LDS, true>, block_threads(2, true), lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 2, LDS, false>, block_threads(2, false), lds_bytes);
+    case 4:
+        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 4, LDS, true>, block_threads(4, true), lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 4, LDS, false>, block_threads(4, false), lds_bytes);
+    case 8:
+        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 8, LDS, true>, block_threads(8, true), lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 8, LDS, false>, block_threads(8, false), lds_bytes);
+    default:
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 16, LDS, false>, block_threads(16, false), lds_bytes);
+    }
+}
+
+template <bool LDS>
+static hipError_t round_occupancy(int model, int waves, bool producers, size_t lds_bytes, int *blocks) {
+    switch (model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        return round_occupancy_w<APEMOST_MODEL_SIMPLESIN, LDS>(waves, producers, lds_bytes, blocks);
+    case APEMOST_MODEL_PULSE:
+        return round_occupancy_w<APEMOST_MODEL_PULSE, LDS>(waves, producers, lds_bytes, blocks);
+    case APEMOST_MODEL_PULSE_VROT:
+        return round_occupancy_w<APEMOST_MODEL_PULSE_VROT, LDS>(waves, producers, lds_bytes, blocks);
+    default:
+        return round_occupancy_w<APEMOST_MODEL_SINE3, LDS>(waves, producers, lds_bytes, blocks);
     }
 }
 
@@ -1225,7 +1286,10 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     a.n_rounds = n_rounds;
     a.round = s->round;
     a.samples = d_samples;
-    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, (u64)n_steps * n_rounds >= 4);
+    bool stage = (u64)n_steps * n_rounds >= 4 || s->cfg.lds_policy == 1;
+    if (n_rounds > 1) // residency decides when workgroups wait for each other
+        stage = s->resident_lds ? stage || !s->resident_plain : false;
+    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, stage);
     if (rc)
         return rc;
     s->cur ^= 1;
