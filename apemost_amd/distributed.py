@@ -86,10 +86,11 @@ class ShardedLadder:
     def launch_round(self, n_steps, samples=None):
         self.launch_rounds(1, n_steps, samples)
 
-    def run_sampler(self, n_rounds, n_swap, samples=None):
+    def run_sampler(self, n_rounds, n_swap, samples=None, finalize=True):
         """run_sampler (src/parallel_tempering.c:392-409) on this shard.  samples: array/tensor
         [n_rounds][n_swap][n_local][n_par+2] or None.  Rounds are batched into one engine launch
-        up to the next swap attempt that needs a neighbour's record."""
+        up to the next swap attempt that needs a neighbour's record.  With finalize=False the last
+        swap attempt stays pending and is applied at the start of the next call."""
         limit = self.e.max_rounds_per_launch()
         r = 0
         while r < n_rounds:
@@ -99,8 +100,8 @@ class ShardedLadder:
                 k += 1
             self.launch_rounds(k, n_swap, None if samples is None else samples[r:r + k])
             r += k
-        if self.swap_pending:
-            self.launch_rounds(1, 0)
+        if finalize and self.swap_pending:
+            self.launch_rounds(1, 0)   # apply the last swap attempt (run_sampler returns after it)
 
 
 class HipShardEngine:

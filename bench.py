@@ -128,7 +128,8 @@ def main():
     ladder.prime()
 
     def one_step():
-        ladder.run_sampler(R, n_swap, samples)
+        # the swap attempt that closes a bench step is applied at the start of the next one
+        ladder.run_sampler(R, n_swap, samples, finalize=False)
 
     def sync_all():
         s.synchronize()
@@ -163,6 +164,17 @@ def main():
     steps_per_launch = (a.steps * R * n_swap * n_local) / max(launches.value, 1)
     achieved_gbs = bytes_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9
     flops_per_step = {"simplesin": 28.0, "sine3": 3 * 24.0 + 4}.get(w.name, 40.0) * w.n_data
+    # HBM bytes per launch from the PMC counters cannot be read inside this process; they are
+    # collected with `rocprofv3 --pmc` on this same command (profiles/README.md) and quoted here
+    # only when the workload is the one they were measured on
+    traffic = None
+    key = "%s/%d/%d/%d/%d/%s" % (w.name, n_local, w.n_data, n_swap, R, "nosamples" if a.no_samples else "samples")
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        if pmc.get("workload_key") == key and world == 1:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "MCMC steps/sec (all chains) on simplesin, 1/2/4/8 MI355X + HBM-roofline %",
         "value": value, "unit": "Metropolis steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -176,7 +188,7 @@ def main():
                    "waves_per_chain": waves, "data_in_lds": lds, "parallelism": "ladder-sharded x%d" % world,
                    "edge_exchanges_rank0": ladder.exchanges},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "pt_round_kernel", "launch_us": launch_ms * 1e3,
                      "algorithmic_bytes_per_launch": bytes_per_step * steps_per_launch,
                      "fp64_valu_frac": flops_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e12
