@@ -22,7 +22,7 @@ class ShardedLadder:
          launch_rounds(n_rounds, n_steps, apply_swap, samples) -- rounds of steps with the swaps
                                                       between them, all inside the local shard
          max_rounds_per_launch()
-         edge_export(side) -> tensor, edge_import(side, tensor)
+         edge_export(side) -> tensor, edge_import(side, tensor), fence()
          swap_pair(round) -> a,  comm_stream() context manager
        `HipShardEngine` below is the product engine; the gloo tests plug in an oracle-backed one."""
 
@@ -47,10 +47,14 @@ class ShardedLadder:
         with self.e.comm_stream():
             send = self.e.edge_export(side)
             recv = send.new_empty(send.shape)
-            # the lower rank sends first; with batch_isend_irecv the order inside the group is free
+            # Edge exchanges are rare (one pair in n_beta per round), so the two hand-overs between
+            # the engine's stream and the communication backend are plain host synchronisations:
+            # correct for every backend, whatever stream it works on.
+            self.e.fence()
             ops = [dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            self.e.fence()
             self.e.edge_import(side, recv)
         self.exchanges += 1
 
@@ -66,9 +70,11 @@ class ShardedLadder:
                     continue
                 send = self.e.edge_export(side)
                 recv = send.new_empty(send.shape)
+                self.e.fence()
                 for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer),
                                                    dist.P2POp(dist.irecv, recv, peer)]):
                     req.wait()
+                self.e.fence()
 
     def _straddles(self, swap_index):
         a = self.e.swap_pair(swap_index)
@@ -119,6 +125,11 @@ class HipShardEngine:
     def comm_stream(self):
         # enqueue the NCCL(=RCCL) ops relative to the engine's own stream: no host sync needed
         return self.torch.cuda.stream(self._ext)
+
+    def fence(self):
+        """everything queued on the engine's stream and on torch's streams of this device is done"""
+        self.s.synchronize()
+        self.torch.cuda.synchronize()
 
     def edge_export(self, side):
         buf = self.torch.empty(self.n_rec, dtype=self.torch.float64, device="cuda")

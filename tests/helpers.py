@@ -74,6 +74,9 @@ class OracleShardEngine:
     def comm_stream(self):
         return self._null()
 
+    def fence(self):
+        pass
+
     def edge_export(self, side):
         c = 0 if side == 0 else self.lad.n_chain - 1
         rec = np.concatenate([[self.lad.beta[c], self.lad.prob[c], self.lad.prob_best[c]],
