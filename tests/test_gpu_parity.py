@@ -273,3 +273,60 @@ def test_sharded_driver_on_one_gpu_batches_rounds_and_matches_oracle():
     np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
     assert dev.swapcount.sum() > 10
     s.close()
+
+
+def test_single_chain_ladder_has_no_swaps():
+    w = small_workloads()["simplesin"]
+    s, dev, samples, lad, rng, ref = _run_both(w, 1, 10, 9, 2)
+    assert_match(dev, lad, rng, what="single chain")
+    assert dev.swapcount[0] == 0 and s.round == (10, False)
+    s.close()
+
+
+def test_pulse_with_five_modes_twelve_parameters():
+    """generic mode count (apps/pulse.c loops over n_par): 63/12 = 5 attempt lanes per parameter"""
+    torch = _torch()
+    rs = np.random.RandomState(5)
+    nu = np.linspace(10, 12, 150)
+    modes = [(10.2 + 0.35 * k, 1.0 + k) for k in range(5)]
+    y = sum(h / (1 + (2 * np.pi * (f - nu) * 4.0) ** 2) for f, h in modes) + 0.05
+    data = np.stack([nu, y * rs.exponential(1.0, 150)], 1)
+    start = [4.0, 0.05] + [v for f, h in modes for v in (f, h)]
+    pmin = [0.1, 0] + [v for _ in modes for v in (10, 0)]
+    pmax = [50, 1] + [v for _ in modes for v in (12, 20)]
+
+    class W:
+        pass
+    w = W()
+    w.model, w.n_par, w.data = wl.MODEL_PULSE, 12, data
+    w.start, w.pmin, w.pmax = np.array(start), np.array(pmin, float), np.array(pmax, float)
+    w.step = (w.pmax - w.pmin) * 0.1
+    s, dev, samples, lad, rng, ref = _run_both(w, 6, 30, 5, 4)
+    assert_match(dev, lad, rng, what="pulse 5 modes")
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    s.close()
+
+
+def test_proposals_far_wider_than_the_prior_box_use_the_wave_parallel_redraw():
+    """step = 6 x range: nearly every prepared attempt leaves [min,max], so the 64-at-a-time redraw
+    path of the proposal runs constantly; attempt indices must still match the oracle's serial loop"""
+    torch = _torch()
+    w = small_workloads()["simplesin"]
+    st, lad, rng = make_pair(w, 4, seed=3)
+    st.step[:] = (w.pmax - w.pmin) * 6.0
+    lad.step[:] = st.step
+    for waves in (1, 8):
+        s = HipSampler(w.model, 4, 4, w.data, seed=3, waves_per_chain=waves)
+        s.set_state(st)
+        d = torch.zeros((60, 4, 6), dtype=torch.float64, device="cuda")
+        s.run_sampler(12, 5, d.data_ptr())
+        s.synchronize()
+        dev = s.get_state()
+        lad2 = orc.Ladder(w.model, 4, 4, w.data)
+        from tests.helpers import to_oracle
+        to_oracle(st, lad2)
+        rng2 = orc.Rng(orc.RNG_STREAMS, 3, lad2)
+        ref = orc.run_sampler(lad2, rng2, 12, 5, record=True)
+        assert_match(dev, lad2, rng2, what="wide steps waves=%d" % waves)
+        np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-9)
+        s.close()
