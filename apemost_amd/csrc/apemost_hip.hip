@@ -155,9 +155,20 @@ __device__ __forceinline__ bool wait_at_least(const u64 *word, u64 want, u64 *ti
 
 // which neighbour's record a chain read at its latest use of each half of the state block, and for
 // which swap index: before the chain overwrites its row in that half it waits for that reader's ack
-struct SwapMemo {
-    int partner[2];
-    u64 index[2];
+struct SwapMemo { // two named slots, not arrays: a run-time subscript would put them in scratch
+    int partner0, partner1;
+    u64 index0, index1;
+    __device__ __forceinline__ int partner(int half) const { return half ? partner1 : partner0; }
+    __device__ __forceinline__ u64 index(int half) const { return half ? index1 : index0; }
+    __device__ __forceinline__ void set(int half, int p, u64 i) {
+        if (half) {
+            partner1 = p;
+            index1 = i;
+        } else {
+            partner0 = p;
+            index0 = i;
+        }
+    }
 };
 
 // tempering_interaction() (src/parallel_tempering_interaction.c:25-42, 87-123, 125-141) as seen
@@ -211,9 +222,9 @@ __device__ __forceinline__ int swap_apply(E &e, const DevArrays &d, const ChainS
 template <class E>
 __device__ __forceinline__ void wait_for_reader(const DevArrays &d, const ChainShape &sh, const SwapMemo &memo,
                                                 int half) {
-    const int p = memo.partner[half];
+    const int p = memo.partner(half);
     if (p >= 0 && p < sh.n_chains)
-        wait_at_least(d.acked() + p, memo.index[half] + 1, d.timeout_word());
+        wait_at_least(d.acked() + p, memo.index(half) + 1, d.timeout_word());
 }
 
 // swap attempt at the start of a launch: both records were stored by the previous launch (or
@@ -229,8 +240,7 @@ __device__ __forceinline__ void swap_at_launch_start(E &e, const DevArrays &d, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the reads above have landed
     if (e.lane == 0)
         st_agent(d.acked() + c, swap_index + 1);
-    memo.partner[half] = partner;
-    memo.index[half] = swap_index;
+    memo.set(half, partner, swap_index);
 }
 
 // swap attempt between two rounds of one launch: the two chains of the pair publish their
@@ -273,8 +283,7 @@ __device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const C
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (e.lane == 0)
         st_agent(d.acked() + c, swap_index + 1);
-    memo.partner[half] = partner;
-    memo.index[half] = swap_index;
+    memo.set(half, partner, swap_index);
 }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
@@ -284,9 +293,10 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
     const int c = blockIdx.x;
     engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
+    e.pin_uniforms();
     SwapMemo memo;
-    memo.partner[0] = memo.partner[1] = -1;
-    memo.index[0] = memo.index[1] = 0;
+    memo.partner0 = memo.partner1 = -1;
+    memo.index0 = memo.index1 = 0;
     if (a.apply_swap)
         swap_at_launch_start(e, a.d, a.sh, c, a.cur, a.round, memo);
     e.producer_prologue();
@@ -297,6 +307,11 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
 #endif
 
     const int n = a.sh.n_par;
+    // each lane's slot in the sample row of its chain, advanced by one row set per step
+    double *my_sample = nullptr;
+    if (a.samples && e.wave == 0 && (e.lane == 63 || (e.is_cand && e.qidx == 0)))
+        my_sample = a.samples + (size_t)c * (n + 2) + (e.lane == 63 ? n : e.grp);
+    const size_t sample_stride = (size_t)a.sh.n_chains * (n + 2);
     for (unsigned r = 0; r < a.n_rounds; r++) {
         if (r > 0) // the swap attempt between round r-1 and round r
             swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
@@ -304,15 +319,15 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
             e.step(a.which);
             if (e.wave == 0) {
                 e.check_best();
-                if (a.samples) {
+                if (my_sample) {
                     // the row the reference prints per step: params ("%.15e"), prob, prob-prior
-                    double *row = a.samples + (((size_t)r * a.n_steps + s) * a.sh.n_chains + c) * (n + 2);
-                    if (e.is_cand && e.qidx == 0)
-                        row[e.grp] = e.cur;
                     if (e.lane == 63) {
-                        row[n] = e.prob;
-                        row[n + 1] = e.prob - e.prior;
+                        my_sample[0] = e.prob;
+                        my_sample[1] = e.prob - e.prior;
+                    } else {
+                        my_sample[0] = e.cur;
                     }
+                    my_sample += sample_stride;
                 }
             }
         }
@@ -399,6 +414,7 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kerne
     const int n = a.sh.n_par;
     engine_setup(e, a.d, a.sh, c, lds);
     chain_load(e, a.d, a.sh, c, a.cur);
+    e.pin_uniforms();
     e.producer_prologue();
     __syncthreads();
     e.producer_first_fetch();
