@@ -31,17 +31,17 @@ struct RoundArgs {
     double *samples; // [n_steps][n_chains][n_par+2] or nullptr
 };
 
-// candidate sets kept in LDS: 4-slot ring with a producer wave, WAVES without
-__host__ __device__ constexpr int cand_slots(int waves) { return waves > 4 ? waves : 4; }
-// two producer wavefronts join every multi-wave workgroup that still fits 1024 threads
+// candidate sets kept in LDS: 8-slot ring with producer waves, WAVES without
+__host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? waves : 8; }
+// three producer wavefronts can join every multi-wave workgroup
 // (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
-__host__ __device__ constexpr bool has_producer(int waves) { return waves > 1 && waves < 16; }
-__host__ __device__ constexpr int block_threads(int waves, bool producers) { return (waves + (producers ? 2 : 0)) * kWave; }
+__host__ __device__ constexpr bool has_producer(int waves) { return waves > 1; }
+__host__ __device__ constexpr int block_threads(int waves, bool producers) { return (waves + (producers ? 3 : 0)) * kWave; }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
 __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
                                              const ChainShape &sh, int c, double *lds) {
-    constexpr int kThreads = (WAVES + (PRODUCER ? 2 : 0)) * kWave;
+    constexpr int kThreads = (WAVES + (PRODUCER ? 3 : 0)) * kWave;
     // Wave roles.  A workgroup's wavefronts are dealt to the CU's four SIMDs cyclically, so
     // with producers the chain owner (role 0) is hardware wave 3 and the producers are hardware
     // waves 1 and 2: three different SIMDs, and the owner's serial code does not share issue
@@ -727,12 +727,13 @@ static int choose_waves(const apemost_hip_config &c) {
     if (c.waves_per_chain > 0)
         return c.waves_per_chain;
     // enough wavefronts to spread the chip's 1024 SIMDs over the resident chains,
-    // but never fewer than 2 data points per lane and never more than 16 waves
+    // but never fewer than 4 data points per lane (a 4-wave workgroup plus its three producer
+    // waves still has the full 256-register budget per lane) and never more than 8 waves
     int by_chip = 1;
-    while (by_chip < 16 && (long long)c.n_chains * by_chip * 2 <= 2048)
+    while (by_chip < 8 && (long long)c.n_chains * by_chip * 2 <= 2048)
         by_chip *= 2;
     int by_data = 1;
-    while (by_data < 16 && c.n_data >= by_data * 2 * kWave * 2)
+    while (by_data < 8 && c.n_data >= by_data * 2 * kWave * 4)
         by_data *= 2;
     int w = by_chip < by_data ? by_chip : by_data;
     // very long data vectors: a few waves per chain even on a full chip (shorter steps, same work)
@@ -797,9 +798,9 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     // producer wavefronts pay while CUs are idle anyway (few chains); beyond one workgroup per
     // CU they only take wave slots from other chains
     s->producers = has_producer(s->waves) && cfg->n_chains <= 256;
-    if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 8 && s->waves != 16) {
+    if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 6 && s->waves != 8) {
         delete s;
-        return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 8 or 16");
+        return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 6 or 8");
     }
     const size_t fixed_lds = (kFixedLdsDoubles + (size_t)cand_slots(s->waves) * 2 * kWave) * sizeof(double);
     const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
@@ -1051,7 +1052,7 @@ static hipError_t launch_w(int waves, KernelKind kind, bool producers, int grid,
     case 8:
         return launch_one<MODEL, 8, LDS>(kind, producers, grid, lds, st, args);
     default:
-        return launch_one<MODEL, 16, LDS>(kind, producers, grid, lds, st, args);
+        return launch_one<MODEL, 6, LDS>(kind, producers, grid, lds, st, args);
     }
 }
 
@@ -1184,7 +1185,7 @@ static hipError_t set_lds_attr_w(int waves, size_t bytes) {
     case 8:
         return set_lds_attr<MODEL, 8>(bytes);
     default:
-        return set_lds_attr<MODEL, 16>(bytes);
+        return set_lds_attr<MODEL, 6>(bytes);
     }
 }
 
@@ -1204,7 +1205,8 @@ static hipError_t round_occupancy_w(int waves, bool producers, size_t lds_bytes,
         return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 8, LDS, true>, block_threads(8, true), lds_bytes)
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 8, LDS, false>, block_threads(8, false), lds_bytes);
     default:
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 16, LDS, false>, block_threads(16, false), lds_bytes);
+        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 6, LDS, true>, block_threads(6, true), lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 6, LDS, false>, block_threads(6, false), lds_bytes);
     }
 }
 

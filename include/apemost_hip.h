@@ -83,7 +83,7 @@ typedef struct {
     int32_t n_chains;        /* chains resident on this device (a shard of the ladder) */
     int32_t n_data;          /* m->data->size1 */
     int32_t n_cols;          /* m->data->size2 (>= 2) */
-    int32_t waves_per_chain; /* wavefronts cooperating on one chain; 0 = choose */
+    int32_t waves_per_chain; /* likelihood wavefronts per chain: 1, 2, 4, 6 or 8; 0 = choose */
     int32_t lds_policy;      /* data vector staged in LDS: 0 = choose, 1 = always (if it fits), 2 = never */
     int32_t reserved;        /* must be 0 */
     int64_t chain_offset;    /* ladder index of local chain 0 */

@@ -57,7 +57,7 @@ def test_swap_pair_host_matches_oracle():
     assert capi.swap_pair(5, 0, 1) == -1
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("waves", [1, 2, 4, 6, 8])
 def test_loglike_golden_vectors(waves, golden_dir):
     # doc/manual.rst:190-213
     data = np.array([[101, 0.67], [102, 1.01], [103, 7.9e-1], [104, 1.34]])
@@ -74,7 +74,7 @@ def test_loglike_golden_vectors(waves, golden_dir):
 
 
 @pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
-@pytest.mark.parametrize("waves", [1, 4, 16])
+@pytest.mark.parametrize("waves", [1, 4, 6])
 def test_loglike_matches_oracle(name, waves):
     w = small_workloads()[name]
     rs = np.random.RandomState(3)
