@@ -54,6 +54,7 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PROD
     e.n_par = sh.n_par;
     e.n_data = sh.n_data;
     e.consts = sh.consts;
+    e.x_abs_max = sh.x_abs_max;
     e.seed = sh.seed;
     e.g = (u64)(sh.chain_offset + c);
     e.parity = 0;
@@ -829,6 +830,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->sh.seed = cfg->seed;
     s->sh.consts.sigma = cfg->sigma;
     s->sh.consts.hmin = cfg->hmin;
+    s->sh.x_abs_max = INFINITY; // until set_data
     HIP_TRY(hipStreamSynchronize(s->stream));
     if ((rc = enable_big_lds(s)))
         return rc;
@@ -929,9 +931,15 @@ extern "C" int apemost_hip_set_data(apemost_hip_sampler *s, const double *data_r
         return fail(APEMOST_HIP_ERR_INVALID, "data is NULL");
     const int n = s->cfg.n_data, nc = s->cfg.n_cols;
     std::vector<double> col((size_t)n * nc);
-    for (int i = 0; i < n; i++)
+    double x_abs_max = 0;
+    for (int i = 0; i < n; i++) {
         for (int j = 0; j < nc; j++)
             col[(size_t)j * n + i] = data_rowmajor[(size_t)i * nc + j];
+        const double ax = std::fabs(data_rowmajor[(size_t)i * nc]);
+        if (!(ax <= x_abs_max)) // also catches NaN
+            x_abs_max = std::isfinite(ax) ? ax : INFINITY;
+    }
+    s->sh.x_abs_max = x_abs_max;
     HIP_TRY(hipMemcpyAsync((void *)s->d.data, col.data(), col.size() * sizeof(double),
                            hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));

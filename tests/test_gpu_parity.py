@@ -330,3 +330,24 @@ def test_proposals_far_wider_than_the_prior_box_use_the_wave_parallel_redraw():
         assert_match(dev, lad2, rng2, what="wide steps waves=%d" % waves)
         np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-9)
         s.close()
+
+
+def test_sine_argument_range_guard():
+    """|2 pi (f x + phi)| >= 2^45: the phase has no significant bits; the engine returns NaN (and the
+    accept test then rejects) instead of a meaningless sine.  Large but representable arguments
+    (Julian-date sized x) still agree with libm to the usual tolerance."""
+    w = wl.simplesin(n_data=50, n_chain=2)
+    big = w.data.copy()
+    big[:, 0] += 2.45e6                       # x ~ JD
+    s = HipSampler(w.model, 4, 2, big)
+    p = [0.9, 0.27, 0.4, 0.5]
+    prob, _ = s.loglike([p], 1.0)
+    ref, _ = orc.loglike(w.model, p, big)
+    assert abs(prob[0] - ref) <= 1e-12 * abs(ref)
+    s.close()
+    huge = w.data.copy()
+    huge[3, 0] = 1e14
+    s = HipSampler(w.model, 4, 2, huge)
+    prob, _ = s.loglike([p], 1.0)
+    assert np.isnan(prob[0])
+    s.close()
