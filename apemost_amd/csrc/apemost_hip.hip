@@ -89,7 +89,7 @@ __device__ __forceinline__ void chain_load(E &e, const DevArrays &d, const Chain
     e.accept = d.accept()[c];
     e.reject = d.reject()[c];
     e.tick = d.ticks()[c];
-    if (e.wave == 0 && e.is_cand) {
+    if (e.wave == 0 && e.cand()) {
         const size_t k = (size_t)c * n + e.grp;
         e.cur = d.params(cur)[(size_t)row * n + e.grp];
         e.best = d.params_best(cur)[(size_t)row * n + e.grp];
@@ -107,7 +107,7 @@ __device__ __forceinline__ void chain_store(const E &e, const DevArrays &d, cons
     const int row = c + 1, n = sh.n_par;
     if (e.wave != 0)
         return;
-    if (e.is_cand && e.qidx == 0) {
+    if (e.cand() && e.qidx == 0) {
         const size_t k = (size_t)c * n + e.grp;
         d.params(dst)[(size_t)row * n + e.grp] = e.cur;
         d.params_best(dst)[(size_t)row * n + e.grp] = e.best;
@@ -204,7 +204,7 @@ __device__ __forceinline__ int swap_apply(E &e, const DevArrays &d, const ChainS
         const double a_best = (g == a) ? e.prob_best : p_best, b_best = (g == a) ? p_best : e.prob_best;
         const bool a_wins = a_best > b_best;
         const bool take_best = (g == a) != a_wins; // this chain receives the other one's best (quirk Q3)
-        if (e.is_cand) {
+        if (e.cand()) {
             const double *pp = d.params(half) + (size_t)partner * n + e.grp;
             const double *pb = d.params_best(half) + (size_t)partner * n + e.grp;
             e.cur = shared ? ld_agent(pp) : *pp;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const C
     }
     const int n = sh.n_par, row = c + 1;
     wait_for_reader<E>(d, sh, memo, half);
-    if (e.is_cand && e.qidx == 0) {
+    if (e.cand() && e.qidx == 0) {
         st_agent(d.params(half) + (size_t)row * n + e.grp, e.cur);
         st_agent(d.params_best(half) + (size_t)row * n + e.grp, e.best);
     }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
     const int n = a.sh.n_par;
     // each lane's slot in the sample row of its chain, advanced by one row set per step
     double *my_sample = nullptr;
-    if (a.samples && e.wave == 0 && (e.lane == 63 || (e.is_cand && e.qidx == 0)))
+    if (a.samples && e.wave == 0 && (e.lane == 63 || (e.cand() && e.qidx == 0)))
         my_sample = a.samples + (size_t)c * (n + 2) + (e.lane == 63 ? n : e.grp);
     const size_t sample_stride = (size_t)a.sh.n_chains * (n + 2);
     for (unsigned r = 0; r < a.n_rounds; r++) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_loglike_kernel(const EvalArgs
     engine_setup(e, d, a.sh, c, lds);
     e.beta_all = a.beta[c];
     e.prior = 0;
-    e.cur = (e.wave == 0 && e.is_cand) ? a.params[(size_t)c * a.sh.n_par + e.grp] : 0.0;
+    e.cur = (e.wave == 0 && e.cand()) ? a.params[(size_t)c * a.sh.n_par + e.grp] : 0.0;
     __syncthreads();
     e.calc_model_current();
     if (e.wave == 0 && e.lane == 0) {
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kerne
             int rescaled = 0, fail = 0;
             if (w0) {
                 int up = 0, clamped = 0, down = 0, too_large = 0;
-                if (e.is_cand) {
+                if (e.cand()) {
                     const double ar = (double)e.pacc / ((double)e.prej + (double)e.pacc);
                     if (ar > rat_limit + 0.05) {
                         up = 1;
