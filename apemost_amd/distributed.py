@@ -110,6 +110,79 @@ class ShardedLadder:
             self.launch_rounds(1, 0)   # apply the last swap attempt (run_sampler returns after it)
 
 
+def calibrate_rest_sharded(sampler, n_global, lo, cfg=None, ladder_kind=0, beta_0=-0.001,
+                           skip_calibrate_allchains=False, dist=None, rank=0, torch=None):
+    """calibrate_rest() (src/parallel_tempering.c:115-207) on a block-partitioned ladder.
+
+    Entry state: rank 0's chain 0 carries the calibrated steps/params of `calibrate_first`
+    (read_calibration_file(chains, 1)), every beta = 1.  Rank 0 (which must hold chains 0 and 1)
+    calibrates chain 1 alone to get the per-parameter stepwidth factors and beta_0, broadcasts
+    (status, beta_0, factors, steps of chain 0, best point of chain 0) -- 3*n_par+2 doubles, the
+    only communication -- and then every rank seeds and calibrates its own chains concurrently,
+    one workgroup per chain.  Returns (status, beta_0, factors)."""
+    import numpy as np
+    from . import capi
+    from .sampler import calc_beta_0, get_chain_beta
+    n_par, n_local = sampler.n_par, sampler.n_chains
+    cfg = cfg or capi.calib_defaults()
+    msg = np.zeros(2 + 3 * n_par)
+    if rank == 0:
+        assert lo == 0 and (n_global == 1 or n_local >= 2), "rank 0 must hold chains 0 and 1"
+        st = sampler.get_state()
+        factors = np.ones(n_par)
+        status = 0
+        if n_global > 1:
+            b0 = calc_beta_0(st, 0, factors) if beta_0 < 0 else beta_0
+            b1 = get_chain_beta(ladder_kind, 1, n_global, b0)
+            st.beta[1], st.swapcount[1] = b1, 0
+            st.step[1] = st.step[0] * b1 ** -0.5
+            st.params[1] = st.params_best[0]
+            sampler.set_state(st, ("beta", "swapcount", "step", "params"))
+            sampler.calc_model(1, 1)
+            stat, _ = sampler.markov_chain_calibrate(1, 1, cfg)
+            status = int(stat[0])
+            st = sampler.get_state()
+            factors = factors * st.beta[1] ** -0.5
+            factors = factors * st.step[0]
+            factors = factors / st.step[1]
+        if beta_0 < 0:
+            beta_0 = calc_beta_0(st, 0, factors)
+        msg[:] = np.concatenate([[status, beta_0], factors, st.step[0], st.params_best[0]])
+    if dist is not None:
+        t = torch.from_numpy(msg)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        msg = t.cpu().numpy()
+    status, beta_0 = int(msg[0]), float(msg[1])
+    factors, step0, best0 = msg[2:2 + n_par], msg[2 + n_par:2 + 2 * n_par], msg[2 + 2 * n_par:]
+    if status != 0:
+        return status, None, None
+    first = 1 if lo == 0 else 0          # chain 0 itself is never touched again
+    if n_local - first > 0:
+        st = sampler.get_state()
+        for i in range(first, n_local):
+            b = get_chain_beta(ladder_kind, lo + i, n_global, beta_0)
+            st.beta[i], st.swapcount[i] = b, 0
+            st.step[i] = step0 * b ** -0.5
+            st.step[i] = st.step[i] * factors
+            st.params[i] = best0
+        sampler.set_state(st, ("beta", "swapcount", "step", "params"))
+        sampler.calc_model(first, n_local - first)
+        stat, _ = sampler.markov_chain_calibrate(first, n_local - first, cfg,
+                                                 burn_in_only=skip_calibrate_allchains)
+        bad = stat[stat != 0]
+        if len(bad):
+            status = int(bad[0])
+    if dist is not None:
+        t = torch.tensor([float(status)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        status = int(t.item())
+    return status, beta_0, factors
+
+
 class HipShardEngine:
     """ShardedLadder engine on top of HipSampler + torch tensors in HBM (plumbing only)."""
 

@@ -16,6 +16,24 @@
 #ifndef CIRCULAR_PARAMS
 #define CIRCULAR_PARAMS 0
 #endif
+
+/* Compile-time variants of the reference that the device engine does not implement: refuse to
+ * build rather than silently sample something else. */
+#ifdef PROPOSAL_LOGISTIC
+#error "PROPOSAL_LOGISTIC: the MI355X engine implements the default Gaussian proposal only"
+#endif
+#ifdef PROPOSAL_UNIFORM
+#error "PROPOSAL_UNIFORM: the MI355X engine implements the default Gaussian proposal only"
+#endif
+#ifdef RANDOMSWAP
+#error "RANDOMSWAP: the MI355X engine implements the default swap schedule (decide_swap_now) only"
+#endif
+#if defined(RWM) || defined(ADAPT)
+#error "RWM / ADAPT: adaptive step widths during the run are not implemented by the MI355X engine"
+#endif
+#if defined(CALIBRATE_MULTILIN) || defined(CALIBRATE_QUADRATIC) || defined(CALIBRATE_ALTERNATE)
+#error "alternate calibrators are not implemented by the MI355X engine (default markov_chain_calibrate_orig only)"
+#endif
 #ifndef ACCURACY_DEVIATION_FACTOR
 #define ACCURACY_DEVIATION_FACTOR 0.25
 #endif

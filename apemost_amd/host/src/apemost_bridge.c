@@ -3,6 +3,7 @@
 #include <string.h>
 #include "apemost_bridge.h"
 #include "parallel_tempering_beta.h"
+#include "markov_chain.h"
 #include "debug.h"
 
 #ifndef SIGMA
@@ -262,9 +263,21 @@ void apemost_ladder_download(apemost_ladder *l) {
     }
 }
 
+/* -DCIRCULAR_PARAMS=1,2,... is a comma list (untestable in the preprocessor): anything but the
+ * default single 0 is refused when the first ladder is opened */
+static void refuse_circular_params(void) {
+    static const unsigned int circular[] = {CIRCULAR_PARAMS, 0};
+    if (circular[0] != 0) {
+        fprintf(stderr, "CIRCULAR_PARAMS: wrapped parameters are not implemented by the MI355X engine\n");
+        exit(1);
+    }
+}
+
 apemost_ladder *apemost_ladder_open(mcmc **chains, unsigned int n_chains) {
     apemost_ladder *l = (apemost_ladder *)calloc(1, sizeof(apemost_ladder));
-    const int model = apemost_detect_model(chains[0]);
+    int model;
+    refuse_circular_params();
+    model = apemost_detect_model(chains[0]);
     l->chains = chains;
     l->n = n_chains;
     l->n_par = chains[0]->n_par;

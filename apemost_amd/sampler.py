@@ -181,39 +181,5 @@ class HipSampler:
         """calibrate_rest() for a whole ladder on this device.  Entry state: chain 0 carries the
         calibrated steps/params (read_calibration_file(chains, 1)), every beta = 1."""
         assert self.n_chains == self.n_chains_global and self.chain_offset == 0
-        n_beta, n_par = self.n_chains, self.n_par
-        st = self.get_state()
-        factors = np.ones(n_par)
-
-        def prepare(i, beta, fac):
-            st.beta[i] = beta
-            st.swapcount[i] = 0
-            st.step[i] = st.step[0] * beta ** -0.5
-            if fac is not None:
-                st.step[i] = st.step[i] * fac
-            st.params[i] = st.params_best[0]
-
-        if n_beta > 1:
-            b0 = calc_beta_0(st, 0, factors) if beta_0 < 0 else beta_0
-            prepare(1, get_chain_beta(ladder_kind, 1, n_beta, b0), None)
-            self.set_state(st, ("beta", "swapcount", "step", "params"))
-            self.calc_model(1, 1)
-            status, _ = self.markov_chain_calibrate(1, 1, cfg)
-            if status[0]:
-                return int(status[0]), None, None
-            st = self.get_state()
-            factors = factors * st.beta[1] ** -0.5
-            factors = factors * st.step[0]
-            factors = factors / st.step[1]
-        if beta_0 < 0:
-            beta_0 = calc_beta_0(st, 0, factors)
-        if n_beta > 1:
-            for i in range(1, n_beta):
-                prepare(i, get_chain_beta(ladder_kind, i, n_beta, beta_0), factors)
-            self.set_state(st, ("beta", "swapcount", "step", "params"))
-            self.calc_model(1, n_beta - 1)
-            status, _ = self.markov_chain_calibrate(1, n_beta - 1, cfg, burn_in_only=skip_calibrate_allchains)
-            bad = status[status != 0]
-            if len(bad):
-                return int(bad[0]), beta_0, factors
-        return 0, beta_0, factors
+        from .distributed import calibrate_rest_sharded
+        return calibrate_rest_sharded(self, self.n_chains, 0, cfg, ladder_kind, beta_0, skip_calibrate_allchains)

@@ -77,3 +77,61 @@ def test_two_processes_one_gpu_equal_whole_ladder(tmp_path):
         assert np.array_equal(np.concatenate([p[f] for p in parts]), getattr(ref, f)), f
     assert np.array_equal(np.concatenate([p["samples"] for p in parts], axis=2), d.cpu().numpy())
     assert sum(int(p["exchanges"]) for p in parts) >= 2
+
+
+def _calib_worker(rank, world, port, n_global, seed, burn, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from apemost_amd import capi
+    from apemost_amd.distributed import calibrate_rest_sharded, shard_bounds
+    from apemost_amd.sampler import HipSampler
+    from apemost_amd.state import LadderState
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = wl.simplesin(n_data=128, n_chain=n_global)
+    lo, hi = shard_bounds(n_global, world, rank)
+    st = LadderState.from_params(n_global, w.start, w.pmin, w.pmax, w.step * 0.2)
+    s = HipSampler(w.model, 4, hi - lo, w.data, seed=seed, chain_offset=lo, n_chains_global=n_global)
+    s.set_state(st.slice(lo, hi))
+    cfg = capi.calib_defaults(burn_in_iterations=burn)
+    status, beta_0, factors = calibrate_rest_sharded(s, n_global, lo, cfg, dist=dist, rank=rank, torch=torch)
+    got = s.get_state()
+    np.savez(os.path.join(out_dir, "calib%d.npz" % rank), status=status, beta_0=beta_0, beta=got.beta, step=got.step,
+             params=got.params, ticks=got.ticks, prob_best=got.prob_best)
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_calibrate_rest_equals_whole_ladder(tmp_path):
+    """calibrate_rest on two shards (two processes, one broadcast of 3*n_par+2 doubles) gives the very
+    same betas, step widths and start points as the whole ladder on one sampler"""
+    import torch.multiprocessing as mp
+    from apemost_amd import capi
+    from apemost_amd.sampler import HipSampler
+    from apemost_amd.state import LadderState
+    n_global, seed, burn, world = 10, 41, 600, 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_calib_worker, args=(r, world, port, n_global, seed, burn, str(tmp_path)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    w = wl.simplesin(n_data=128, n_chain=n_global)
+    st = LadderState.from_params(n_global, w.start, w.pmin, w.pmax, w.step * 0.2)
+    s = HipSampler(w.model, 4, n_global, w.data, seed=seed)
+    s.set_state(st)
+    status, beta_0, factors = s.calibrate_rest(capi.calib_defaults(burn_in_iterations=burn))
+    ref = s.get_state()
+    s.close()
+    parts = [np.load(os.path.join(str(tmp_path), "calib%d.npz" % r)) for r in range(world)]
+    assert status == 0 and all(int(p["status"]) == 0 for p in parts)
+    assert all(float(p["beta_0"]) == beta_0 for p in parts)
+    for f in ("beta", "step", "params", "ticks", "prob_best"):
+        assert np.array_equal(np.concatenate([p[f] for p in parts]), getattr(ref, f)), f
+    assert ref.beta[0] == 1.0 and abs(ref.beta[-1] - beta_0) < 1e-15
