@@ -20,8 +20,10 @@ int main(int argc, char **argv) {
         calibrate_rest();
     else if (strcmp(argv[1], "run") == 0)
         prepare_and_run_sampler(MAX_ITERATIONS, argc == 3 && strcmp(argv[2], "--append") == 0);
-    else if (strcmp(argv[1], "analyse") == 0)
+    else if (strcmp(argv[1], "analyse") == 0) {
+        analyse_marginal_distributions();
         analyse_data_probability();
+    }
     else
         return 1;
     return 0;

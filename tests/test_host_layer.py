@@ -85,6 +85,7 @@ def test_c_application_workflow_equals_python_mirror_and_oracle(tmp_path):
     env = dict(os.environ, APEMOST_SEED="5")
     for phase in ("calibrate_first", "calibrate_rest", "run"):
         subprocess.check_call([exe, phase], cwd=str(work), env=env, stdout=subprocess.DEVNULL)
+    out = subprocess.check_output([exe, "analyse"], cwd=str(work), env=env).decode()
     c_calib = (work / "calibration_results").read_text()
     c_accept = (work / "acceptance_rate.dump").read_text().strip().splitlines()[-1].split()
     c_amp = np.loadtxt(str(work / "amplitude-chain-0.prob.dump"))
@@ -128,6 +129,22 @@ def test_c_application_workflow_equals_python_mirror_and_oracle(tmp_path):
     samples = d.cpu().numpy()
     assert np.array_equal(c_amp, _rt(samples[:, 0, 0]))         # "%.15e" text of the same doubles
     np.testing.assert_allclose(c_prob[:, 0], samples[:, 3, 4], rtol=2e-6)   # "%6e" keeps 7 digits
+
+    # analyse phase (host post-processing of the dump files): histogram of chain 0 integrates to the
+    # bin width (the reference's scaling), evidence = rectangle rule over beta of <prob-prior>/beta
+    h = np.loadtxt(str(work / "amplitude.histogram"))
+    assert h.shape == (200, 3) and abs(h[:, 2].sum() - (w.pmax[0] - w.pmin[0]) / 200) < 1e-12
+    hist, _ = np.histogram(samples[:, 0, 0], bins=200, range=(w.pmin[0], w.pmax[0]))
+    np.testing.assert_allclose(h[:, 2], hist * ((w.pmax[0] - w.pmin[0]) / 200 / iters), atol=1e-12)
+    betas = np.array([float(l.split()[0]) for l in c_calib.strip().splitlines()])
+    means = np.array([np.loadtxt(str(work / ("prob-chain%d.dump" % i)))[:, 1].mean() / betas[i] for i in range(n_beta)])
+    evidence, prev = 0.0, 0.0
+    for j in range(n_beta - 1, -1, -1):
+        evidence += means[j] * (betas[j] - prev)
+        prev = betas[j]
+    got = float(re.search(r"\] (-?[0-9.]+)\n", out).group(1))
+    assert abs(got - evidence) < 1e-4 * abs(evidence) + 1e-5
+    assert os.path.exists(str(work / "marginal_distributions.gnuplot")) and "mcmc error estimate of amplitude" in out
 
     # and the oracle agrees with the run phase (tolerance: DESIGN.md 7)
     lad = orc.Ladder(w.model, n_beta, 4, data)
