@@ -33,15 +33,15 @@ struct RoundArgs {
 
 // candidate sets kept in LDS: 8-slot ring with producer waves, WAVES without
 __host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? waves : 8; }
-// three producer wavefronts can join every multi-wave workgroup
+// candidate production as a side duty of waves 1-3 (workgroups of at least 4 waves)
 // (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
-__host__ __device__ constexpr bool has_producer(int waves) { return waves > 1; }
-__host__ __device__ constexpr int block_threads(int waves, bool producers) { return (waves + (producers ? 3 : 0)) * kWave; }
+__host__ __device__ constexpr bool has_producer(int waves) { return waves >= 4; }
+__host__ __device__ constexpr int block_threads(int waves, bool) { return waves * kWave; }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
 __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
                                              const ChainShape &sh, int c, double *lds) {
-    constexpr int kThreads = (WAVES + (PRODUCER ? 3 : 0)) * kWave;
+    constexpr int kThreads = WAVES * kWave;
     // Wave roles.  A workgroup's wavefronts are dealt to the CU's four SIMDs cyclically, so
     // with producers the chain owner (role 0) is hardware wave 3 and the producers are hardware
     // waves 1 and 2: three different SIMDs, and the owner's serial code does not share issue
@@ -728,13 +728,13 @@ static int choose_waves(const apemost_hip_config &c) {
     if (c.waves_per_chain > 0)
         return c.waves_per_chain;
     // enough wavefronts to spread the chip's 1024 SIMDs over the resident chains,
-    // but never fewer than 4 data points per lane (a 4-wave workgroup plus its three producer
-    // waves still has the full 256-register budget per lane) and never more than 8 waves
+    // but never fewer than 2 data points per lane and never more than 8 waves (two per SIMD,
+    // 512 threads: the full 256-register budget per lane)
     int by_chip = 1;
     while (by_chip < 8 && (long long)c.n_chains * by_chip * 2 <= 2048)
         by_chip *= 2;
     int by_data = 1;
-    while (by_data < 8 && c.n_data >= by_data * 2 * kWave * 4)
+    while (by_data < 8 && c.n_data >= by_data * 2 * kWave * 2)
         by_data *= 2;
     int w = by_chip < by_data ? by_chip : by_data;
     // very long data vectors: a few waves per chain even on a full chip (shorter steps, same work)
@@ -796,9 +796,8 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->d_iters = nullptr;
     s->calib_capacity = 0;
     s->waves = choose_waves(*cfg);
-    // producer wavefronts pay while CUs are idle anyway (few chains); beyond one workgroup per
-    // CU they only take wave slots from other chains
-    s->producers = has_producer(s->waves) && cfg->n_chains <= 256;
+    // waves 1-3 produce the proposal candidates in the serial window of each step
+    s->producers = has_producer(s->waves);
     if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 6 && s->waves != 8) {
         delete s;
         return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 6 or 8");
