@@ -351,3 +351,27 @@ def test_sine_argument_range_guard():
     prob, _ = s.loglike([p], 1.0)
     assert np.isnan(prob[0])
     s.close()
+
+
+def test_maximum_parameter_count():
+    """n_par = 62 (APEMOST_HIP_MAX_PAR): one attempt lane per parameter, pulse with 30 modes"""
+    torch = _torch()
+    rs = np.random.RandomState(9)
+    n_modes = 30
+    nu = np.linspace(10, 12, 90)
+    modes = [(10.03 + 0.065 * k, 0.5 + 0.1 * k) for k in range(n_modes)]
+    y = sum(h / (1 + (2 * np.pi * (f - nu) * 4.0) ** 2) for f, h in modes) + 0.05
+    data = np.stack([nu, y * rs.exponential(1.0, len(nu))], 1)
+
+    class W:
+        pass
+    w = W()
+    w.model, w.n_par, w.data = wl.MODEL_PULSE, 2 + 2 * n_modes, data
+    w.start = np.array([4.0, 0.05] + [v for f, h in modes for v in (f, h)])
+    w.pmin = np.array([0.1, 0] + [v for _ in modes for v in (10, 0)], float)
+    w.pmax = np.array([50, 1] + [v for _ in modes for v in (12, 20)], float)
+    w.step = (w.pmax - w.pmin) * 0.02
+    s, dev, samples, lad, rng, ref = _run_both(w, 3, 6, 4, 2)
+    assert_match(dev, lad, rng, what="62 parameters")
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    s.close()
