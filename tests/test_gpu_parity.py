@@ -414,3 +414,39 @@ def test_posterior_and_acceptance_agree_with_reference_stream_mode():
         (mg, eg), (mr, er) = batch_stats(g), batch_stats(r)
         assert abs(mg - mr) < 5 * np.hypot(eg, er) + 1e-12, (p, mg, mr, eg, er)
         assert abs(g.std() - r.std()) < 0.25 * r.std(), (p, g.std(), r.std())
+
+
+@pytest.mark.parametrize("name,n_chain,n_data,n_swap,n_rounds", [
+    ("sine3", 1024, 8192, 1, 6),          # BASELINE config 3
+    ("pulse", 2048, 1024, 1, 40),         # config 4, one GPU's worth of chains at full ladder size
+    ("pulse_vrot", 256, 65536, 1, 3),     # config 5 data vector (1 MiB, read through L2), fewer chains
+])
+def test_large_configs_size_independent_properties(name, n_chain, n_data, n_swap, n_rounds):
+    """full-size BASELINE shapes: run-to-run bit identity, counter conservation, bounds, and agreement
+    with the oracle on a subset of chains (the oracle is too slow for all of them)"""
+    torch = _torch()
+    w = wl.by_name(name, n_data=n_data, n_chain=n_chain)
+    st, _, _ = make_pair(w, n_chain, seed=13)
+    outs = []
+    for rep in range(2):
+        s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=13)
+        s.set_state(st)
+        d = torch.zeros((n_rounds * n_swap, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
+        s.run_sampler(n_rounds, n_swap, d.data_ptr())
+        s.synchronize()
+        outs.append((s.get_state(), d.cpu().numpy()))
+        s.close()
+    (a, sa), (b, sb) = outs
+    assert np.array_equal(sa, sb) and np.array_equal(a.params, b.params) and np.array_equal(a.prob, b.prob)
+    n = n_rounds * n_swap
+    assert np.all(a.accept + a.reject == n) and np.all(a.ticks == n) and np.all(a.n_iter == n)
+    assert np.all(sa[..., :w.n_par] >= w.pmin) and np.all(sa[..., :w.n_par] <= w.pmax)
+    assert np.all(np.isfinite(sa)) and a.swapcount.sum() <= n_rounds
+    # oracle check without swaps influence: recompute the final log-posterior of a few chains
+    for c in (0, n_chain // 2, n_chain - 1):
+        if a.accept[c] == 0:
+            continue
+        prob, prior = orc.loglike(w.model, a.params[c], w.data, beta=a.beta[c])
+        # prob belongs to the last accepted point = current params unless a swap moved params since
+        if a.swapcount[max(c - 1, 0):c + 1].sum() == 0:
+            assert abs(a.prob[c] - prob) <= 1e-11 * abs(prob), (c, a.prob[c], prob)
