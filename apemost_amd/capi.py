@@ -30,7 +30,7 @@ class Config(C.Structure):
                 ("n_cols", C.c_int32), ("waves_per_chain", C.c_int32), ("lds_policy", C.c_int32),
                 ("reserved", C.c_int32), ("chain_offset", C.c_int64),
                 ("n_chains_global", C.c_int64), ("seed", C.c_uint64), ("sigma", C.c_double),
-                ("hmin", C.c_double)]
+                ("hmin", C.c_double), ("circular_params", C.c_uint64)]
 
 
 class StateView(C.Structure):

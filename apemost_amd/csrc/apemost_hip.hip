@@ -55,6 +55,7 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PROD
     e.n_data = sh.n_data;
     e.consts = sh.consts;
     e.x_abs_max = sh.x_abs_max;
+    e.circular = sh.circular;
     e.seed = sh.seed;
     e.g = (u64)(sh.chain_offset + c);
     e.parity = 0;
@@ -758,6 +759,8 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
         return fail(APEMOST_HIP_ERR_INVALID, "shard [%lld,%lld) outside ladder of %lld chains",
                     (long long)cfg->chain_offset, (long long)(cfg->chain_offset + cfg->n_chains),
                     (long long)cfg->n_chains_global);
+    if (cfg->n_par < 64 && (cfg->circular_params >> cfg->n_par) != 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "circular_params names a parameter beyond n_par");
     if (cfg->n_chains_global > 2000000)
         return fail(APEMOST_HIP_ERR_INVALID, "n_beta*1000 must fit an int (interaction.c:92)");
     switch (cfg->model) {
@@ -829,6 +832,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->sh.seed = cfg->seed;
     s->sh.consts.sigma = cfg->sigma;
     s->sh.consts.hmin = cfg->hmin;
+    s->sh.circular = cfg->circular_params;
     s->sh.x_abs_max = INFINITY; // until set_data
     HIP_TRY(hipStreamSynchronize(s->stream));
     if ((rc = enable_big_lds(s)))

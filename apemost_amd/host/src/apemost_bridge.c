@@ -40,6 +40,17 @@ static unsigned long env_seed(void) {
 
 static parallel_tempering_mcmc *pt(const mcmc *m) { return (parallel_tempering_mcmc *)m->additional_data; }
 
+/* -DCIRCULAR_PARAMS=1,2,...: 1-based indices of the parameters that wrap around their range
+ * (reference src/markov_chain.h:34-46); the default single 0 means none */
+static uint64_t circular_mask(void) {
+    static const unsigned int circular[] = {CIRCULAR_PARAMS, 0};
+    uint64_t mask = 0;
+    unsigned int j;
+    for (j = 0; circular[j] != 0; j++)
+        mask |= (uint64_t)1 << (circular[j] - 1);
+    return mask;
+}
+
 static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned int n_chains, long chain_offset,
                                            long n_global) {
     apemost_hip_config cfg;
@@ -60,6 +71,7 @@ static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned in
     cfg.seed = env_seed();
     cfg.sigma = SIGMA;
     cfg.hmin = HMIN;
+    cfg.circular_params = circular_mask();
     apemost_hip_or_die(apemost_hip_create(&cfg, &s), "apemost_hip_create");
     if (m->data->tda != m->data->size2) {
         fprintf(stderr, "data matrix must be contiguous\n");
@@ -263,21 +275,9 @@ void apemost_ladder_download(apemost_ladder *l) {
     }
 }
 
-/* -DCIRCULAR_PARAMS=1,2,... is a comma list (untestable in the preprocessor): anything but the
- * default single 0 is refused when the first ladder is opened */
-static void refuse_circular_params(void) {
-    static const unsigned int circular[] = {CIRCULAR_PARAMS, 0};
-    if (circular[0] != 0) {
-        fprintf(stderr, "CIRCULAR_PARAMS: wrapped parameters are not implemented by the MI355X engine\n");
-        exit(1);
-    }
-}
-
 apemost_ladder *apemost_ladder_open(mcmc **chains, unsigned int n_chains) {
     apemost_ladder *l = (apemost_ladder *)calloc(1, sizeof(apemost_ladder));
-    int model;
-    refuse_circular_params();
-    model = apemost_detect_model(chains[0]);
+    const int model = apemost_detect_model(chains[0]);
     l->chains = chains;
     l->n = n_chains;
     l->n_par = chains[0]->n_par;

@@ -10,16 +10,6 @@
 #include "gsl_helper.h"
 #include "debug.h"
 
-/* CIRCULAR_PARAMS is a comma list in the reference (e.g. -DCIRCULAR_PARAMS=1,2), so it cannot be
- * tested by the preprocessor; anything but the default single 0 is refused at start-up. */
-static void refuse_circular_params(void) {
-    static const unsigned int circular[] = {CIRCULAR_PARAMS, 0};
-    if (circular[0] != 0) {
-        fprintf(stderr, "CIRCULAR_PARAMS: wrapped parameters are not implemented by the MI355X engine\n");
-        exit(1);
-    }
-}
-
 void restart_from_best(mcmc *m) {
     set_params(m, dup_vector(get_params_best(m)));
     set_prob(m, get_prob_best(m));
@@ -47,7 +37,6 @@ void markov_chain_step(mcmc *m) {
     const double prob_best = m->prob_best;
     gsl_vector *best = dup_vector(m->params_best);
     mcmc_check(m);
-    refuse_circular_params();
     l = apemost_single(m);
     apemost_ladder_upload(l);
     apemost_hip_or_die(apemost_hip_launch_round(apemost_ladder_sampler(l), 1, 0, NULL), "markov_chain_step");

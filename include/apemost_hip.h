@@ -91,6 +91,8 @@ typedef struct {
     uint64_t seed;           /* rocRAND Philox4x32-10 seed (role of GSL_RNG_SEED) */
     double sigma;            /* SIGMA, apps/simplesin.c:8-10 */
     double hmin;             /* HMIN, apps/pulse.c:8-10 */
+    uint64_t circular_params; /* bit p set: parameter p wraps around [min,max] instead of being
+                               * redrawn (-DCIRCULAR_PARAMS, src/markov_chain.c:241-265) */
 } apemost_hip_config;
 
 /* Host-side structure-of-arrays view of n_chains chains; any pointer may be NULL

@@ -293,16 +293,27 @@ void orc_calc_model(orc_state *s, int c) {
  * Single-chain Metropolis (src/markov_chain.c)
  * ========================================================================= */
 
-/* do_step_for, non-circular branch: src/markov_chain.c:226-240 */
+/* do_step_for: src/markov_chain.c:226-270.  Default: redraw until inside [min,max] (:235-240).
+ * With CIRCULAR_PARAMS (:241-265) the first jump is kept; if it leaves the box a circular
+ * parameter wraps it (min + mod_double(new-min, max-min)) and any other parameter falls back to
+ * the redraw loop -- for those the two branches are the same rule. */
 static void do_step_for(orc_state *s, orc_rng *r, int c, int p) {
     size_t k = (size_t)c * s->n_par + p;
     const double step = s->step[k], old_value = s->params[k];
     const double max = s->pmax[k], min = s->pmin[k];
+    const int circular = (int)((s->circular >> p) & 1);
     double new_value;
     if (r->kind == ORC_RNG_GLOBAL_MT) {
-        do {
-            new_value = old_value + orc_gaussian(r, step);
-        } while (new_value > max || new_value < min);
+        new_value = old_value + orc_gaussian(r, step);
+        if (new_value > max || new_value < min) {
+            if (circular) {
+                new_value = min + orc_mod_double(new_value - min, max - min);
+            } else {
+                do {
+                    new_value = old_value + orc_gaussian(r, step);
+                } while (new_value > max || new_value < min);
+            }
+        }
     } else {
         uint64_t q = 0;
         for (;; q++) {
@@ -312,6 +323,10 @@ static void do_step_for(orc_state *s, orc_rng *r, int c, int p) {
             new_value = old_value + step * y * sq;
             if (!(new_value > max || new_value < min))
                 break;
+            if (circular) {
+                new_value = min + orc_mod_double(new_value - min, max - min);
+                break;
+            }
         }
     }
     s->params[k] = new_value;

@@ -97,6 +97,7 @@ typedef struct {
     const double *data;     /* row-major [n_data][n_cols], shared by all chains */
     double sigma;           /* SIGMA (simplesin.c:8-10), default 0.5 */
     double hmin;            /* HMIN (pulse.c:8-10), default 1e-6 */
+    uint64_t circular;      /* bit p: parameter p is in -DCIRCULAR_PARAMS (markov_chain.h:34-46) */
     /* per chain */
     double *params;         /* [n_chain][n_par] */
     double *params_best;    /* [n_chain][n_par] */

@@ -36,7 +36,7 @@ class _Rng(C.Structure):
 class _State(C.Structure):
     _fields_ = [("n_chain", C.c_int), ("n_par", C.c_int), ("model", C.c_int),
                 ("n_data", C.c_int), ("n_cols", C.c_int), ("chain_offset", C.c_int64),
-                ("data", _dp), ("sigma", C.c_double), ("hmin", C.c_double),
+                ("data", _dp), ("sigma", C.c_double), ("hmin", C.c_double), ("circular", C.c_uint64),
                 ("params", _dp), ("params_best", _dp), ("step", _dp), ("pmin", _dp),
                 ("pmax", _dp), ("params_accepts", _up), ("params_rejects", _up),
                 ("beta", _dp), ("prob", _dp), ("prior", _dp), ("prob_best", _dp),
@@ -158,6 +158,7 @@ class Ladder:
         assert self.data.ndim == 2
         self.chain_offset = int(chain_offset)
         self.sigma, self.hmin = float(sigma), float(hmin)
+        self.circular = 0   # bit p: parameter p wraps (CIRCULAR_PARAMS)
         z2 = lambda dt: np.zeros((n_chain, n_par), dtype=dt)
         z1 = lambda dt: np.zeros((n_chain,), dtype=dt)
         self.params, self.params_best, self.step = z2(np.float64), z2(np.float64), z2(np.float64)
@@ -194,6 +195,7 @@ class Ladder:
         st.chain_offset = self.chain_offset
         st.data = self.data.ctypes.data_as(_dp)
         st.sigma, st.hmin = self.sigma, self.hmin
+        st.circular = self.circular
         for n in _F64:
             a = getattr(self, n)
             assert a.flags.c_contiguous and a.dtype == np.float64, n

@@ -450,3 +450,30 @@ def test_large_configs_size_independent_properties(name, n_chain, n_data, n_swap
         # prob belongs to the last accepted point = current params unless a swap moved params since
         if a.swapcount[max(c - 1, 0):c + 1].sum() == 0:
             assert abs(a.prob[c] - prob) <= 1e-11 * abs(prob), (c, a.prob[c], prob)
+
+
+def test_circular_parameters_wrap_like_the_reference():
+    """-DCIRCULAR_PARAMS: a circular parameter (the phase) wraps around its range instead of being
+    redrawn (src/markov_chain.c:241-265); same attempt indices and wrapped values as the oracle"""
+    torch = _torch()
+    w = small_workloads()["simplesin"]
+    st, lad, rng = make_pair(w, 6, seed=8)
+    st.step[:, 2] = 0.8          # phase jumps of the order of its [0,1] range: wraps all the time
+    lad.step[:] = st.step
+    lad.circular = 1 << 2
+    s = HipSampler(w.model, 4, 6, w.data, seed=8, circular_params=1 << 2)
+    s.set_state(st)
+    d = torch.zeros((200, 6, 6), dtype=torch.float64, device="cuda")
+    s.run_sampler(20, 10, d.data_ptr())
+    s.synchronize()
+    dev = s.get_state()
+    ref = orc.run_sampler(lad, rng, 20, 10, record=True)
+    assert_match(dev, lad, rng, what="circular")
+    np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-9)
+    # and it really is a different chain from the redraw rule
+    lad2 = orc.Ladder(w.model, 6, 4, w.data)
+    from tests.helpers import to_oracle
+    to_oracle(st, lad2)
+    orc.run_sampler(lad2, orc.Rng(orc.RNG_STREAMS, 8, lad2), 20, 10)
+    assert not np.array_equal(lad2.params, lad.params)
+    s.close()
