@@ -31,10 +31,11 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
-def build_stamps(verbose=False):
-    """diagnostic twin of the library with in-kernel s_memtime stamps (tools/stamp_profile.py)"""
-    out = os.path.join(HERE, "libapemost_hip_stamps.so")
-    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_STAMPS", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out,
+def build_stamps(verbose=False, wave=0):
+    """diagnostic twin of the library with in-kernel s_memtime stamps (tools/stamp_profile.py);
+    `wave` selects the wave of workgroup 0 whose step segments are timed, -1 = a timeline of all waves"""
+    out = os.path.join(HERE, "libapemost_hip_stamps%s.so" % ("" if wave == 0 else "_tl" if wave < 0 else "_w%d" % wave))
+    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_STAMPS", "-DAPEMOST_STAMP_WAVE=%d" % wave, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out,
                                  os.path.join(CSRC, "apemost_hip.hip")]
     if verbose:
         print(" ".join(cmd))

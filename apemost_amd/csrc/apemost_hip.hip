@@ -1560,6 +1560,14 @@ extern "C" int apemost_hip_debug_stamps(unsigned long long *out16) {
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero));
     return APEMOST_HIP_OK;
 }
+// steps x 16 waves x points s_memtime values of workgroup 0 (zero = stamp not reached)
+extern "C" int apemost_hip_debug_timeline(unsigned long long *out, int *steps, int *points) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * kTimelineSteps * 16 * kTimelinePoints));
+    *steps = kTimelineSteps;
+    *points = kTimelinePoints;
+    return APEMOST_HIP_OK;
+}
 #endif
 
 extern "C" int apemost_hip_timer_begin(apemost_hip_sampler *s) {

@@ -133,10 +133,21 @@ class HipSampler:
                                               prob.ctypes.data_as(dp), prior.ctypes.data_as(dp)))
         return prob, prior
 
+    def _adopt(self, d_samples):
+        """The sampler launches on its own stream.  A sample buffer that torch has just created
+        (torch.zeros fills it on torch's current stream) must be complete before the first kernel
+        writes rows into it, or the fill may land on top of them."""
+        if d_samples and d_samples != getattr(self, "_last_samples", 0):
+            import torch
+            torch.cuda.current_stream().synchronize()
+        self._last_samples = d_samples
+
     def launch_round(self, n_steps, apply_swap, d_samples=0):
+        self._adopt(d_samples)
         capi.check(self.L.apemost_hip_launch_round(self._h, n_steps, int(apply_swap), d_samples))
 
     def launch_rounds(self, n_rounds, n_steps, apply_swap, d_samples=0):
+        self._adopt(d_samples)
         capi.check(self.L.apemost_hip_launch_rounds(self._h, n_rounds, n_steps, int(apply_swap), d_samples))
 
     @property
@@ -146,10 +157,12 @@ class HipSampler:
         return v.value
 
     def markov_chain_step_for(self, param, n_steps=1, d_samples=0):
+        self._adopt(d_samples)
         capi.check(self.L.apemost_hip_launch_round_for(self._h, n_steps, param, d_samples))
 
     def run_sampler(self, n_rounds, n_swap, d_samples=0):
         """n_rounds x {n_swap steps per chain, one swap attempt}; asynchronous."""
+        self._adopt(d_samples)
         capi.check(self.L.apemost_hip_run(self._h, n_rounds, n_swap, d_samples))
 
     def edge_export(self, side, d_buf):

@@ -8,7 +8,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["APEMOST_HIP_LIB"] = os.path.join(ROOT, "apemost_amd", "libapemost_hip_stamps.so")
+STAMP_WAVE = int(os.environ.get("APEMOST_STAMP_WAVE", "0"))  # build_stamps(wave=...) made the twin
+os.environ["APEMOST_HIP_LIB"] = os.environ.get("APEMOST_STAMP_LIB") or os.path.join(
+    ROOT, "apemost_amd", "libapemost_hip_stamps%s.so" % ("" if STAMP_WAVE == 0 else "_tl" if STAMP_WAVE < 0 else "_w%d" % STAMP_WAVE))
 
 import numpy as np  # noqa: E402
 from apemost_amd import capi, workloads as wl  # noqa: E402
@@ -16,7 +18,25 @@ from apemost_amd.sampler import HipSampler, get_chain_beta  # noqa: E402
 from apemost_amd.state import LadderState  # noqa: E402
 
 SEG = ["bookkeeping", "refill", "propose", "barrier A", "likelihood terms", "partials+finish", "wave reduce",
-       "barrier B", "accept"]
+       "barrier B", "accept", "-", "-", "duty window"]
+# stamps in the order a step passes them
+ORDER = [0, 1, 2, 3, 4, 6, 7, 5, 8, 11]
+NAME = {0: "start", 1: "refill", 2: "proposed", 3: "A out", 4: "terms", 6: "reduced", 7: "B out",
+        5: "finish", 8: "accept", 11: "end"}
+
+
+def timeline(L, waves):
+    """APEMOST_STAMP_WAVE=-1 twin: cycles since the step's first stamp, per wave"""
+    out = (C.c_uint64 * (4 * 16 * 12))()
+    steps, points = C.c_int(), C.c_int()
+    L.apemost_hip_debug_timeline(out, C.byref(steps), C.byref(points))
+    for st in range(steps.value):
+        rows = [[out[(st * 16 + w) * points.value + i] for i in range(points.value)] for w in range(waves)]
+        t0 = min(v for r in rows for v in r if v)
+        print(" step %d   %s" % (st, " ".join("%8s" % NAME[i] for i in ORDER)))
+        for w in range(waves):
+            print("   wave %d %s" % (w, " ".join("%8d" % (rows[w][i] - t0) if rows[w][i] else "       -" for i in ORDER)))
+
 
 
 def main():
@@ -40,9 +60,15 @@ def main():
         n_steps = 200 * 15
         s.run_sampler(200, 15)
         L.apemost_hip_debug_stamps(out)
-        tot = sum(out[:9])
+        if STAMP_WAVE < 0:
+            timeline(L, waves)
+            s.close()
+            continue
+        tot = sum(out[:10]) + out[11]
         print("waves=%d  %s  cycles/step=%.0f" % (waves, name, tot / n_steps))
         for i, nm in enumerate(SEG):
+            if nm == "-":
+                continue
             print("   %-20s %8.0f cyc/step  %5.1f %%" % (nm, out[i] / n_steps, 100.0 * out[i] / tot))
         s.close()
 
