@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--lds", type=int, default=0, help="0 choose, 1 stage the data vector in LDS, 2 read it through L2")
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
+    ap.add_argument("--no-calibrate", action="store_true", help="skip the device calibration before the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
     return ap.parse_args()
 
@@ -118,6 +119,15 @@ def main():
     s = HipSampler(w.model, w.n_par, n_local, w.data, seed=2024, device=local_rank, chain_offset=lo,
                    n_chains_global=n_global, waves_per_chain=a.waves, lds_policy=a.lds)
     s.set_state(st)
+    calibrated = None
+    if not a.no_calibrate:
+        # markov_chain_calibrate (burn-in + step-width calibration towards TARGET_ACCEPTANCE_RATE) for
+        # every chain at its own beta, as calibrate_rest leaves a ladder: the timed steps then accept at
+        # the rate of a production run instead of the ~0 of guessed step widths
+        s.calc_model(0, n_local)
+        status, _ = s.markov_chain_calibrate(0, n_local)
+        calibrated = int((status == 0).sum())
+    acc0 = s.get_state()
     waves, lds = s.geometry
     samples = None
     if not a.no_samples:
@@ -156,6 +166,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    acc1 = s.get_state()
+    d_acc = (acc1.accept - acc0.accept).astype(np.float64)
+    d_rej = (acc1.reject - acc0.reject).astype(np.float64)
+    acceptance = float(np.mean(d_acc / np.maximum(d_acc + d_rej, 1)))
     total_steps = a.steps * R * n_swap * n_global
     value = total_steps / dt
     # roofline of the dominant kernel (pt_round_kernel): ALGORITHMIC bytes per launch / avg launch duration
@@ -186,7 +200,8 @@ def main():
                                 "off" if a.no_samples else "on"),
                    "chains_per_gpu": n_local, "n_data": w.n_data, "n_swap": n_swap, "rounds_per_step": R,
                    "waves_per_chain": waves, "data_in_lds": lds, "parallelism": "ladder-sharded x%d" % world,
-                   "edge_exchanges_rank0": ladder.exchanges},
+                   "edge_exchanges_rank0": ladder.exchanges,
+                   "device_calibrated_chains_rank0": calibrated, "acceptance_rate_rank0": acceptance},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "pt_round_kernel", "launch_us": launch_ms * 1e3,
@@ -196,7 +211,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(w, st, n_swap, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(w, acc0, n_swap, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
