@@ -42,14 +42,12 @@ template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
 __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
                                              const ChainShape &sh, int c, double *lds) {
     constexpr int kThreads = WAVES * kWave;
-    // Wave roles.  A workgroup's wavefronts are dealt to the CU's four SIMDs cyclically, so
-    // with producers the chain owner (role 0) is hardware wave 3 and the producers are hardware
-    // waves 1 and 2: three different SIMDs, and the owner's serial code does not share issue
-    // slots with candidate generation.
-    constexpr int kWavesInBlock = kThreads / kWave;
-    const int hw_wave = threadIdx.x / kWave;
+    // Wave roles.  A workgroup's wavefronts are dealt to the CU's four SIMDs cyclically (wave w and
+    // w+4 share one, tools/hwid_probe.hip): wave 0 owns the chain, waves 1-3 -- the other three
+    // SIMDs -- produce the candidates as a side duty, so the owner's serial code does not share
+    // issue slots with candidate generation.
     e.lane = threadIdx.x & (kWave - 1);
-    e.wave = hw_wave;
+    e.wave = threadIdx.x / kWave;
     e.tid = e.wave * kWave + e.lane;
     e.n_par = sh.n_par;
     e.n_data = sh.n_data;

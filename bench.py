@@ -190,7 +190,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     out = {
-        "metric": "MCMC steps/sec (all chains) on simplesin, 1/2/4/8 MI355X + HBM-roofline %",
+        "metric": "MCMC steps/sec (all chains) on %s, 1/2/4/8 MI355X + HBM-roofline %%" % w.name,
         "value": value, "unit": "Metropolis steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
