@@ -62,6 +62,8 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PROD
     e.s_cand = (double2 *)(lds + kFixedLdsDoubles);
     double *s_data = lds + kFixedLdsDoubles + cand_slots(WAVES) * 2 * kWave;
     e.setup_lanes();
+    if (d.f != nullptr) // a resident chain: its prior box may make the per-step argument check void
+        e.m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
     if (LDS_DATA) {
         // stage the data vector once per launch: coalesced HBM/L2 reads, SoA in LDS
         for (int i = threadIdx.x; i < 2 * sh.n_data; i += kThreads)
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
         swap_at_launch_start(e, a.d, a.sh, c, a.cur, a.round, memo);
     e.producer_prologue();
     __syncthreads();
+    e.cache_rows();
     e.producer_first_fetch();
 #ifdef APEMOST_STAMPS
     e.stamps_begin();
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const Round
     Engine<MODEL, WAVES, LDS_DATA> e;
     const int c = a.first + blockIdx.x;
     engine_setup(e, a.d, a.sh, c, lds);
+    e.m.clear_box(); // caller-supplied parameters may lie outside their prior box
     chain_load(e, a.d, a.sh, c, a.cur);
     __syncthreads();
     e.calc_model_current();
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kerne
     e.pin_uniforms();
     e.producer_prologue();
     __syncthreads();
+    e.cache_rows();
     e.producer_first_fetch();
     const bool w0 = (e.wave == 0);
     const apemost_hip_calib_config &cfg = a.cfg;
