@@ -1,5 +1,14 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+#!/usr/bin/env python3
+"""Diagnostic: run-to-run bit identity of a BASELINE config 3 run (four repetitions), with the
+fields that differ if any do."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from apemost_amd import workloads as wl
 from apemost_amd.sampler import HipSampler
