@@ -731,19 +731,18 @@ static bool choose_lds(const apemost_hip_config &c, size_t lds_bytes) {
 static int choose_waves(const apemost_hip_config &c) {
     if (c.waves_per_chain > 0)
         return c.waves_per_chain;
-    // enough wavefronts to spread the chip's 1024 SIMDs over the resident chains,
-    // but never fewer than 2 data points per lane and never more than 8 waves (two per SIMD,
-    // 512 threads: the full 256-register budget per lane)
-    int by_chip = 1;
-    while (by_chip < 8 && (long long)c.n_chains * by_chip * 2 <= 2048)
-        by_chip *= 2;
+    // Measured on one MI355X (simplesin, 1024 points, steps/s by waves 1/2/4/8):
+    //    128 chains  -   /  -   / 1.23 / 1.33 e8      512 chains  2.07 / 2.10 / 2.59 / 1.97 e8
+    //    256 chains  1.09 / 1.46 / 2.22 / 1.82 e8    1024 chains  3.98 / 3.29 / 2.84 / 2.07 e8
+    // (sine3 1024 x 8192: 3.5e7 with 1 wave, 3.1e7 with 2; pulse_vrot 2048 x 65536: 4.2 / 3.9 / 4.0 /
+    // 3.5 e6.)  A chain's step is a latency chain: while CUs are idle more waves per chain shorten
+    // it; once every SIMD has a wave, a chain per wave without barriers does more.
+    int by_chip = c.n_chains <= 128 ? 8 : c.n_chains <= 512 ? 4 : c.n_chains < 1024 ? 2 : 1;
+    // never fewer than 2 data points per lane
     int by_data = 1;
     while (by_data < 8 && c.n_data >= by_data * 2 * kWave * 2)
         by_data *= 2;
-    int w = by_chip < by_data ? by_chip : by_data;
-    // very long data vectors: a few waves per chain even on a full chip (shorter steps, same work)
-    const int by_length = c.n_data >= 4 * 16384 ? 4 : (c.n_data >= 2 * 16384 ? 2 : 1);
-    return w > by_length ? w : by_length;
+    return by_chip < by_data ? by_chip : by_data;
 }
 
 extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sampler **out) {
