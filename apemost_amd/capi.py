@@ -12,6 +12,7 @@ import numpy as np
 from . import build as _build
 
 ABI_VERSION = 1
+FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_CALIBRATION = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -28,7 +29,7 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("model", C.c_int32),
                 ("n_par", C.c_int32), ("n_chains", C.c_int32), ("n_data", C.c_int32),
                 ("n_cols", C.c_int32), ("waves_per_chain", C.c_int32), ("lds_policy", C.c_int32),
-                ("reserved", C.c_int32), ("chain_offset", C.c_int64),
+                ("flags", C.c_int32), ("chain_offset", C.c_int64),
                 ("n_chains_global", C.c_int64), ("seed", C.c_uint64), ("sigma", C.c_double),
                 ("hmin", C.c_double), ("circular_params", C.c_uint64)]
 

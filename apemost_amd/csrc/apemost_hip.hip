@@ -62,6 +62,8 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PROD
     e.s_cand = (double2 *)(lds + kFixedLdsDoubles);
     double *s_data = lds + kFixedLdsDoubles + cand_slots(WAVES) * 2 * kWave;
     e.setup_lanes();
+    if (threadIdx.x == 0)
+        *e.fail_flag() = 0; // ordered before its first use by the barrier every kernel has after setup
     if (d.f != nullptr) // a resident chain: its prior box may make the per-step argument check void
         e.m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
     if (LDS_DATA) {
@@ -342,6 +344,8 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
         a.d.n_iter()[c] += (u64)a.n_steps * a.n_rounds; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
     if (e.wave == 0)
         wait_for_reader<decltype(e)>(a.d, a.sh, memo, a.cur ^ 1);
+    if (e.tid == 0 && *e.fail_flag())
+        st_agent(a.d.timeout_word(), 3);
     chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
 }
 
@@ -564,6 +568,8 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kerne
     if (e.tid == 0) {
         a.status[blockIdx.x] = status;
         a.iters[blockIdx.x] = sweeps;
+        if (*e.fail_flag())
+            st_agent(a.d.timeout_word(), 3);
     }
     // calibration leaves the chain in place: same half of the double buffer
     chain_store(e, a.d, a.sh, c, a.cur, true);
@@ -663,6 +669,8 @@ struct apemost_hip_sampler {
     int *d_status;
     u64 *d_iters;
     int calib_capacity;
+    bool cooperative;    // multi-round launches through hipLaunchCooperativeKernel
+    bool handoff_failed; // an in-launch hand-off timed out once: single-round launches from then on
 };
 
 extern "C" const char *apemost_hip_last_error(void) { return g_last_error.c_str(); }
@@ -713,8 +721,8 @@ template <class T>
 static int dev_alloc(apemost_hip_sampler *s, T **p, size_t count) {
     void *q = nullptr;
     HIP_TRY(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    s->allocations.push_back(q); // owned from here on, whatever fails next
     HIP_TRY(hipMemsetAsync(q, 0, (count ? count : 1) * sizeof(T), s->stream));
-    s->allocations.push_back(q);
     *p = (T *)q;
     return APEMOST_HIP_OK;
 }
@@ -745,68 +753,33 @@ static int choose_waves(const apemost_hip_config &c) {
     return by_chip < by_data ? by_chip : by_data;
 }
 
-extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sampler **out) {
-    if (!cfg || !out)
-        return fail(APEMOST_HIP_ERR_INVALID, "cfg/out is NULL");
-    *out = nullptr;
-    if (cfg->abi_version != APEMOST_HIP_ABI_VERSION)
-        return fail(APEMOST_HIP_ERR_INVALID, "ABI version %d, library has %d", cfg->abi_version,
-                    APEMOST_HIP_ABI_VERSION);
-    if (cfg->n_par < 1 || cfg->n_par > APEMOST_HIP_MAX_PAR)
-        return fail(APEMOST_HIP_ERR_INVALID, "n_par %d outside [1,%d]", cfg->n_par, APEMOST_HIP_MAX_PAR);
-    if (cfg->n_chains < 1 || cfg->n_data < 1 || cfg->n_cols < 2)
-        return fail(APEMOST_HIP_ERR_INVALID, "n_chains %d, n_data %d, n_cols %d invalid", cfg->n_chains,
-                    cfg->n_data, cfg->n_cols);
-    if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->n_chains > cfg->n_chains_global)
-        return fail(APEMOST_HIP_ERR_INVALID, "shard [%lld,%lld) outside ladder of %lld chains",
-                    (long long)cfg->chain_offset, (long long)(cfg->chain_offset + cfg->n_chains),
-                    (long long)cfg->n_chains_global);
-    if (cfg->n_par < 64 && (cfg->circular_params >> cfg->n_par) != 0)
-        return fail(APEMOST_HIP_ERR_INVALID, "circular_params names a parameter beyond n_par");
-    if (cfg->n_chains_global > 2000000)
-        return fail(APEMOST_HIP_ERR_INVALID, "n_beta*1000 must fit an int (interaction.c:92)");
-    switch (cfg->model) {
-    case APEMOST_MODEL_SIMPLESIN:
-        if (cfg->n_par != 4)
-            return fail(APEMOST_HIP_ERR_INVALID, "simplesin needs n_par = 4");
-        break;
-    case APEMOST_MODEL_SINE3:
-        if (cfg->n_par != 10)
-            return fail(APEMOST_HIP_ERR_INVALID, "sine3 needs n_par = 10");
-        break;
-    case APEMOST_MODEL_PULSE:
-        if (cfg->n_par < 4 || (cfg->n_par - 2) % 2 != 0)
-            return fail(APEMOST_HIP_ERR_INVALID, "pulse needs n_par = 2 + 2*modes");
-        break;
-    case APEMOST_MODEL_PULSE_VROT:
-        if (cfg->n_par != 7)
-            return fail(APEMOST_HIP_ERR_INVALID, "pulse_vrot needs n_par = 7");
-        break;
-    default:
-        return fail(APEMOST_HIP_ERR_UNSUPPORTED, "unknown device model %d", cfg->model);
-    }
-    int rc = apemost_hip_device_info(cfg->device, nullptr, 0, nullptr, nullptr);
-    if (rc != APEMOST_HIP_OK)
-        return rc;
-    HIP_TRY(hipSetDevice(cfg->device));
+// everything a sampler owns on the device; safe on a half-built sampler
+static void release(apemost_hip_sampler *s) {
+    if (s->stream)
+        hipStreamSynchronize(s->stream);
+    for (void *p : s->allocations)
+        hipFree(p);
+    if (s->d_status)
+        hipFree(s->d_status);
+    if (s->d_iters)
+        hipFree(s->d_iters);
+    if (s->ev0)
+        hipEventDestroy(s->ev0);
+    if (s->ev1)
+        hipEventDestroy(s->ev1);
+    if (s->stream)
+        hipStreamDestroy(s->stream);
+    delete s;
+}
 
-    apemost_hip_sampler *s = new apemost_hip_sampler();
-    s->cfg = *cfg;
-    s->cur = 0;
-    s->round = 0;
-    s->swap_pending = 0;
-    s->launches = 0;
-    s->launches_at_begin = 0;
-    s->d_status = nullptr;
-    s->d_iters = nullptr;
-    s->calib_capacity = 0;
-    s->waves = choose_waves(*cfg);
+// the part of apemost_hip_create that can fail after the sampler object exists
+static int create_body(apemost_hip_sampler *s) {
+    const apemost_hip_config *cfg = &s->cfg;
+    int rc;
     // waves 1-3 produce the proposal candidates in the serial window of each step
     s->producers = has_producer(s->waves);
-    if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 6 && s->waves != 8) {
-        delete s;
+    if (s->waves != 1 && s->waves != 2 && s->waves != 4 && s->waves != 6 && s->waves != 8)
         return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 6 or 8");
-    }
     const size_t fixed_lds = (kFixedLdsDoubles + (size_t)cand_slots(s->waves) * 2 * kWave) * sizeof(double);
     const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
     s->lds_data = fixed_lds + data_lds <= 160 * 1024 - 1024 && cfg->lds_policy != 2 &&
@@ -857,6 +830,78 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
             s->resident_plain = true;
         }
         s->resident_ok = s->resident_lds || s->resident_plain;
+        s->cooperative = (cfg->flags & APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH) && prop.cooperativeLaunch;
+        if (cfg->flags & APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES)
+            s->resident_ok = false;
+    }
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sampler **out) {
+    if (!cfg || !out)
+        return fail(APEMOST_HIP_ERR_INVALID, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->abi_version != APEMOST_HIP_ABI_VERSION)
+        return fail(APEMOST_HIP_ERR_INVALID, "ABI version %d, library has %d", cfg->abi_version,
+                    APEMOST_HIP_ABI_VERSION);
+    if (cfg->n_par < 1 || cfg->n_par > APEMOST_HIP_MAX_PAR)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_par %d outside [1,%d]", cfg->n_par, APEMOST_HIP_MAX_PAR);
+    if (cfg->n_chains < 1 || cfg->n_data < 1 || cfg->n_cols < 2)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_chains %d, n_data %d, n_cols %d invalid", cfg->n_chains,
+                    cfg->n_data, cfg->n_cols);
+    if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->n_chains > cfg->n_chains_global)
+        return fail(APEMOST_HIP_ERR_INVALID, "shard [%lld,%lld) outside ladder of %lld chains",
+                    (long long)cfg->chain_offset, (long long)(cfg->chain_offset + cfg->n_chains),
+                    (long long)cfg->n_chains_global);
+    if (cfg->n_par < 64 && (cfg->circular_params >> cfg->n_par) != 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "circular_params names a parameter beyond n_par");
+    if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH))
+        return fail(APEMOST_HIP_ERR_INVALID, "unknown bits in flags: 0x%x", (unsigned)cfg->flags);
+    if (cfg->n_chains_global > 2000000)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_beta*1000 must fit an int (interaction.c:92)");
+    switch (cfg->model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        if (cfg->n_par != 4)
+            return fail(APEMOST_HIP_ERR_INVALID, "simplesin needs n_par = 4");
+        break;
+    case APEMOST_MODEL_SINE3:
+        if (cfg->n_par != 10)
+            return fail(APEMOST_HIP_ERR_INVALID, "sine3 needs n_par = 10");
+        break;
+    case APEMOST_MODEL_PULSE:
+        if (cfg->n_par < 4 || (cfg->n_par - 2) % 2 != 0)
+            return fail(APEMOST_HIP_ERR_INVALID, "pulse needs n_par = 2 + 2*modes");
+        break;
+    case APEMOST_MODEL_PULSE_VROT:
+        if (cfg->n_par != 7)
+            return fail(APEMOST_HIP_ERR_INVALID, "pulse_vrot needs n_par = 7");
+        break;
+    default:
+        return fail(APEMOST_HIP_ERR_UNSUPPORTED, "unknown device model %d", cfg->model);
+    }
+    int rc = apemost_hip_device_info(cfg->device, nullptr, 0, nullptr, nullptr);
+    if (rc != APEMOST_HIP_OK)
+        return rc;
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    apemost_hip_sampler *s = new apemost_hip_sampler();
+    s->cfg = *cfg;
+    s->cur = 0;
+    s->round = 0;
+    s->swap_pending = 0;
+    s->launches = 0;
+    s->launches_at_begin = 0;
+    s->d_status = nullptr;
+    s->d_iters = nullptr;
+    s->calib_capacity = 0;
+    s->stream = nullptr;
+    s->ev0 = s->ev1 = nullptr;
+    s->handoff_failed = false;
+    s->waves = choose_waves(*cfg);
+    rc = create_body(s);
+    if (rc != APEMOST_HIP_OK) {
+        release(s); // the stream, the events and every allocation made so far
+        return rc;
     }
     *out = s;
     return APEMOST_HIP_OK;
@@ -866,17 +911,7 @@ extern "C" int apemost_hip_destroy(apemost_hip_sampler *s) {
     if (!s)
         return APEMOST_HIP_OK;
     hipSetDevice(s->cfg.device);
-    hipStreamSynchronize(s->stream);
-    for (void *p : s->allocations)
-        hipFree(p);
-    if (s->d_status)
-        hipFree(s->d_status);
-    if (s->d_iters)
-        hipFree(s->d_iters);
-    hipEventDestroy(s->ev0);
-    hipEventDestroy(s->ev1);
-    hipStreamDestroy(s->stream);
-    delete s;
+    release(s);
     return APEMOST_HIP_OK;
 }
 
@@ -887,15 +922,25 @@ extern "C" int apemost_hip_destroy(apemost_hip_sampler *s) {
         HIP_TRY(hipSetDevice((s)->cfg.device));                                                  \
     } while (0)
 
-// in-launch swap hand-offs spin with a bound; a hit is reported here
+// Words the kernels raise instead of spinning for ever: 1 = an in-launch swap hand-off timed out (a
+// partner workgroup was not resident), 2 = an in-launch swap picked a pair that straddles the shard,
+// 3 = a proposal found no point inside [min,max] in 2^24 attempts.  The results of that launch are
+// void.  The word is cleared here so that the sampler can be reloaded (set_state) and used again;
+// after a hand-off timeout it only issues single-round launches, which never wait for anybody.
 static int check_handoff(apemost_hip_sampler *s) {
     u64 word = 0;
     HIP_TRY(hipMemcpyAsync(&word, s->d.timeout_word(), sizeof word, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (word != 0)
-        return fail(APEMOST_HIP_ERR_RUNTIME, "in-launch swap hand-off failed (code %llu): the results of that launch are void",
-                    (unsigned long long)word);
-    return APEMOST_HIP_OK;
+    if (word == 0)
+        return APEMOST_HIP_OK;
+    HIP_TRY(hipMemsetAsync(s->d.timeout_word(), 0, sizeof(u64), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (word == 1)
+        s->handoff_failed = true;
+    return fail(APEMOST_HIP_ERR_RUNTIME, "%s (code %llu): the results of that launch are void%s",
+                word == 3 ? "a proposal found no point inside its prior box"
+                          : "in-launch swap hand-off failed",
+                (unsigned long long)word, word == 1 ? "; falling back to one round per launch" : "");
 }
 
 extern "C" int apemost_hip_synchronize(apemost_hip_sampler *s) {
@@ -992,8 +1037,34 @@ static int xfer_state(apemost_hip_sampler *s, const apemost_hip_state_view *v, b
     return APEMOST_HIP_OK;
 }
 
+// A prior box with min > max can never be hit: the reference's redraw loop (src/markov_chain.c:235-240)
+// would spin on the host, the kernel's on the GPU.  Refuse it at the door.
+static int check_box(apemost_hip_sampler *s, const apemost_hip_state_view *v) {
+    if (!v->pmin && !v->pmax)
+        return APEMOST_HIP_OK;
+    const size_t count = (size_t)s->cfg.n_chains * s->cfg.n_par;
+    std::vector<double> other;
+    const double *lo = v->pmin, *hi = v->pmax;
+    if (!lo || !hi) { // only one side comes with this view: the other one is what the device holds
+        other.resize(count);
+        HIP_TRY(hipMemcpyAsync(other.data(), lo ? s->d.pmax() : s->d.pmin(), count * sizeof(double),
+                               hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        (lo ? hi : lo) = other.data();
+    }
+    for (size_t k = 0; k < count; k++)
+        if (!(lo[k] <= hi[k]))
+            return fail(APEMOST_HIP_ERR_INVALID, "chain %zu parameter %zu: min %g > max %g (or NaN)",
+                        k / s->cfg.n_par, k % s->cfg.n_par, lo[k], hi[k]);
+    return APEMOST_HIP_OK;
+}
+
 extern "C" int apemost_hip_set_state(apemost_hip_sampler *s, const apemost_hip_state_view *v) {
-    return xfer_state(s, v, true);
+    CHECK_S(s);
+    if (!v)
+        return fail(APEMOST_HIP_ERR_INVALID, "state view is NULL");
+    const int rc = check_box(s, v);
+    return rc ? rc : xfer_state(s, v, true);
 }
 extern "C" int apemost_hip_get_state(apemost_hip_sampler *s, const apemost_hip_state_view *v) {
     int rc = xfer_state(s, v, false);
@@ -1022,12 +1093,22 @@ extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, in
 enum KernelKind { K_ROUND, K_CALC, K_EVAL, K_CALIB };
 
 template <int MODEL, int WAVES, bool LDS>
-static hipError_t launch_one(KernelKind kind, bool producers, int grid, size_t lds, hipStream_t st, const void *args) {
+static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int grid, size_t lds, hipStream_t st,
+                             const void *args) {
     const dim3 g(grid), b(WAVES * kWave);
     constexpr bool kCanProduce = has_producer(WAVES);
     const dim3 bp(block_threads(WAVES, kCanProduce)); // + producer waves
     switch (kind) {
     case K_ROUND:
+        if (coop) {
+            // the runtime places the whole grid at once or refuses the launch
+            void *params[] = {const_cast<void *>(args)};
+            if (kCanProduce && producers)
+                return hipLaunchCooperativeKernel((const void *)pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>, g, bp,
+                                                  params, (unsigned int)lds, st);
+            return hipLaunchCooperativeKernel((const void *)pt_round_kernel<MODEL, WAVES, LDS, false>, g, b, params,
+                                              (unsigned int)lds, st);
+        }
         if (kCanProduce && producers)
             hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
         else
@@ -1053,47 +1134,50 @@ static hipError_t launch_one(KernelKind kind, bool producers, int grid, size_t l
 }
 
 template <int MODEL, bool LDS>
-static hipError_t launch_w(int waves, KernelKind kind, bool producers, int grid, size_t lds, hipStream_t st,
+static hipError_t launch_w(int waves, KernelKind kind, bool producers, bool coop, int grid, size_t lds, hipStream_t st,
                            const void *args) {
     switch (waves) {
     case 1:
-        return launch_one<MODEL, 1, LDS>(kind, producers, grid, lds, st, args);
+        return launch_one<MODEL, 1, LDS>(kind, producers, coop, grid, lds, st, args);
     case 2:
-        return launch_one<MODEL, 2, LDS>(kind, producers, grid, lds, st, args);
+        return launch_one<MODEL, 2, LDS>(kind, producers, coop, grid, lds, st, args);
     case 4:
-        return launch_one<MODEL, 4, LDS>(kind, producers, grid, lds, st, args);
+        return launch_one<MODEL, 4, LDS>(kind, producers, coop, grid, lds, st, args);
     case 8:
-        return launch_one<MODEL, 8, LDS>(kind, producers, grid, lds, st, args);
+        return launch_one<MODEL, 8, LDS>(kind, producers, coop, grid, lds, st, args);
     default:
-        return launch_one<MODEL, 6, LDS>(kind, producers, grid, lds, st, args);
+        return launch_one<MODEL, 6, LDS>(kind, producers, coop, grid, lds, st, args);
     }
 }
 
 template <int MODEL>
-static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, bool producers, int grid, size_t lds,
+static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, bool producers, bool coop, int grid, size_t lds,
                            hipStream_t st, const void *args) {
-    return lds_data ? launch_w<MODEL, true>(waves, kind, producers, grid, lds, st, args)
-                    : launch_w<MODEL, false>(waves, kind, producers, grid, lds, st, args);
+    return lds_data ? launch_w<MODEL, true>(waves, kind, producers, coop, grid, lds, st, args)
+                    : launch_w<MODEL, false>(waves, kind, producers, coop, grid, lds, st, args);
 }
 
 // stage_data: a launch that walks the data vector only a few times (n_swap < 4, single
 // likelihood evaluations) reads it through L2 instead of copying it into LDS first
-static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true) {
+static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true,
+                  bool coop = false) {
     hipError_t err;
     const bool lds_data = s->lds_data && stage_data;
     const size_t lds_bytes = lds_data ? s->lds_bytes : s->lds_fixed_bytes;
+    const int w = s->waves;
+    const bool pr = s->producers;
     switch (s->cfg.model) {
     case APEMOST_MODEL_SIMPLESIN:
-        err = launch_m<APEMOST_MODEL_SIMPLESIN>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_SIMPLESIN>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
         break;
     case APEMOST_MODEL_PULSE:
-        err = launch_m<APEMOST_MODEL_PULSE>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_PULSE>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
         break;
     case APEMOST_MODEL_PULSE_VROT:
-        err = launch_m<APEMOST_MODEL_PULSE_VROT>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_PULSE_VROT>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
         break;
     default:
-        err = launch_m<APEMOST_MODEL_SINE3>(lds_data, s->waves, kind, s->producers, grid, lds_bytes, s->stream, args);
+        err = launch_m<APEMOST_MODEL_SINE3>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
         break;
     }
     if (err != hipSuccess)
@@ -1124,17 +1208,10 @@ extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int
     return launch(s, K_CALC, count, &a, false);
 }
 
-extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params,
-                                   const double *beta, double *prob, double *prior) {
-    CHECK_S(s);
-    if (n < 1 || !params || !beta || !prob)
-        return fail(APEMOST_HIP_ERR_INVALID, "loglike: bad arguments");
+static int loglike_on_device(apemost_hip_sampler *s, int32_t n, const double *params, const double *beta,
+                             double *prob, double *prior, double *d_params, double *d_beta, double *d_prob,
+                             double *d_prior) {
     const size_t np = s->cfg.n_par;
-    double *d_params, *d_beta, *d_prob, *d_prior;
-    HIP_TRY(hipMalloc((void **)&d_params, n * np * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&d_beta, n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&d_prob, n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&d_prior, n * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(d_params, params, n * np * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(d_beta, beta, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
     EvalArgs a;
@@ -1144,17 +1221,30 @@ extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const doub
     a.beta = d_beta;
     a.prob = d_prob;
     a.prior = d_prior;
-    int rc = launch(s, K_EVAL, n, &a, false);
-    if (!rc) {
-        HIP_TRY(hipMemcpyAsync(prob, d_prob, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        if (prior)
-            HIP_TRY(hipMemcpyAsync(prior, d_prior, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+    const int rc = launch(s, K_EVAL, n, &a, false);
+    if (rc) {
+        hipStreamSynchronize(s->stream);
+        return rc;
     }
-    hipFree(d_params);
-    hipFree(d_beta);
-    hipFree(d_prob);
-    hipFree(d_prior);
+    HIP_TRY(hipMemcpyAsync(prob, d_prob, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (prior)
+        HIP_TRY(hipMemcpyAsync(prior, d_prior, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const double *params,
+                                   const double *beta, double *prob, double *prior) {
+    CHECK_S(s);
+    if (n < 1 || !params || !beta || !prob)
+        return fail(APEMOST_HIP_ERR_INVALID, "loglike: bad arguments");
+    const size_t np = s->cfg.n_par;
+    // one scratch block: params [n][np], beta [n], prob [n], prior [n]
+    double *scratch = nullptr;
+    HIP_TRY(hipMalloc((void **)&scratch, (size_t)n * (np + 3) * sizeof(double)));
+    double *d_params = scratch, *d_beta = scratch + (size_t)n * np, *d_prob = d_beta + n, *d_prior = d_prob + n;
+    const int rc = loglike_on_device(s, n, params, beta, prob, prior, d_params, d_beta, d_prob, d_prior);
+    hipFree(scratch);
     return rc;
 }
 
@@ -1286,7 +1376,7 @@ extern "C" int apemost_hip_launch_round_for(apemost_hip_sampler *s, uint32_t n_s
 // Multi-round launches hand swap records from workgroup to workgroup inside the launch, which
 // is only safe when every workgroup of the grid is resident at once.
 static int max_rounds_per_launch(apemost_hip_sampler *s) {
-    return s->resident_ok ? 64 : 1;
+    return (s->resident_ok && !s->handoff_failed) ? 64 : 1;
 }
 
 extern "C" int apemost_hip_max_rounds_per_launch(apemost_hip_sampler *s, int32_t *max_rounds) {
@@ -1320,7 +1410,13 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     bool stage = (u64)n_steps * n_rounds >= 4 || s->cfg.lds_policy == 1;
     if (n_rounds > 1) // residency decides when workgroups wait for each other
         stage = s->resident_lds ? stage || !s->resident_plain : false;
-    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, stage);
+    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, stage, s->cooperative && n_rounds > 1);
+    if (rc && s->cooperative && n_rounds > 1) {
+        // the runtime cannot place the grid at once: single-round launches from now on
+        s->resident_ok = false;
+        return fail(APEMOST_HIP_ERR_INVALID, "cooperative launch of %d workgroups refused (%s); this sampler now allows 1 round per launch",
+                    s->cfg.n_chains, apemost_hip_last_error());
+    }
     if (rc)
         return rc;
     s->cur ^= 1;
@@ -1341,11 +1437,13 @@ extern "C" int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32
                     "apemost_hip_run needs the whole ladder on one device; sharded ladders drive "
                     "apemost_hip_launch_rounds + apemost_hip_edge_*");
     const size_t row = (size_t)s->cfg.n_chains * (s->cfg.n_par + 2);
-    const uint64_t per_launch = n_swap > 0 ? (uint64_t)max_rounds_per_launch(s) : 1;
     for (uint64_t r = 0; r < n_rounds;) {
+        const uint64_t per_launch = n_swap > 0 ? (uint64_t)max_rounds_per_launch(s) : 1;
         const uint64_t k = n_rounds - r < per_launch ? n_rounds - r : per_launch;
         int rc = launch_round_impl(s, (uint32_t)k, n_swap, s->swap_pending, -1,
                                    d_samples ? d_samples + r * n_swap * row : nullptr);
+        if (rc && k > 1 && max_rounds_per_launch(s) == 1)
+            continue; // a refused cooperative launch changed nothing: go on one round at a time
         if (rc)
             return rc;
         r += k;
@@ -1372,7 +1470,7 @@ extern "C" int apemost_hip_samples_read(apemost_hip_sampler *s, const double *d_
     const size_t bytes = (size_t)n_steps * s->cfg.n_chains * (s->cfg.n_par + 2) * sizeof(double);
     HIP_TRY(hipMemcpyAsync(host, d_samples, bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return APEMOST_HIP_OK;
+    return check_handoff(s); // rows of a void launch are not handed to the caller as samples
 }
 
 extern "C" int apemost_hip_samples_free(apemost_hip_sampler *s, double *d_samples) {

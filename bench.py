@@ -7,6 +7,8 @@ ROUNDS_PER_STEP rounds of {n_swap Metropolis steps per chain + one swap attempt}
 (run_sampler's loop body, src/parallel_tempering.c:392-409), sample rows written to HBM.
 Workload at every N: BASELINE config 2 per GPU -- simplesin, 128 chains x 1024 data points per
 GPU (weak scaling: the ladder has 128*N chains, block-partitioned over the ranks).
+`--config 3|4|5` selects the other GPU configs of BASELINE.json (per-GPU share of the ladder,
+table CONFIGS below); the default line the driver records stays config 2.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -23,23 +25,40 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6  # fp64 vector peak
 
+# BASELINE.json configs as one GPU sees them: workload, chains per GPU, data points, n_swap
+# (0 = the reference's rule 2000/n_beta of the per-GPU ladder; ladders beyond 2000 chains need an
+# explicit value), burn-in of the device calibration that precedes the timed steps
+CONFIGS = {
+    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000),
+    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000),
+    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000),     # 2048 / 8 GPUs
+    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600),  # 16384 / 8 GPUs
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="simplesin")
-    ap.add_argument("--chains-per-gpu", type=int, default=128)
-    ap.add_argument("--n-data", type=int, default=1024)
-    ap.add_argument("--n-swap", type=int, default=0, help="0 = reference rule 2000/n_beta of the per-GPU ladder")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number")
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--chains-per-gpu", type=int, default=None)
+    ap.add_argument("--n-data", type=int, default=None)
+    ap.add_argument("--n-swap", type=int, default=None, help="0 = reference rule 2000/n_beta of the per-GPU ladder")
+    ap.add_argument("--burn-in", type=int, default=None, help="BURN_IN_ITERATIONS of the device calibration")
+    ap.add_argument("--flags", type=int, default=0, help="apemost_hip_config.flags")
     ap.add_argument("--rounds-per-step", type=int, default=32)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--lds", type=int, default=0, help="0 choose, 1 stage the data vector in LDS, 2 read it through L2")
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the device calibration before the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
-    return ap.parse_args()
+    a = ap.parse_args()
+    for k, v in CONFIGS[a.config].items():
+        if getattr(a, k, None) is None:
+            setattr(a, k, v)
+    return a
 
 
 def host_cores():
@@ -107,6 +126,7 @@ def main():
     lo = rank * n_local
     w = wl.by_name(a.workload, n_data=a.n_data, n_chain=n_global)
     n_swap = a.n_swap or max(1, 2000 // n_local)
+
     R = a.rounds_per_step
 
     # a calibrated-looking ladder: chebyshev betas, steps = steps0 * beta^-1/2
@@ -117,7 +137,7 @@ def main():
         st.step[i] = np.minimum(st.step[i] * b ** -0.5, w.pmax - w.pmin)
 
     s = HipSampler(w.model, w.n_par, n_local, w.data, seed=2024, device=local_rank, chain_offset=lo,
-                   n_chains_global=n_global, waves_per_chain=a.waves, lds_policy=a.lds)
+                   n_chains_global=n_global, waves_per_chain=a.waves, lds_policy=a.lds, flags=a.flags)
     s.set_state(st)
     calibrated = None
     if not a.no_calibrate:
@@ -125,7 +145,7 @@ def main():
         # every chain at its own beta, as calibrate_rest leaves a ladder: the timed steps then accept at
         # the rate of a production run instead of the ~0 of guessed step widths
         s.calc_model(0, n_local)
-        status, _ = s.markov_chain_calibrate(0, n_local)
+        status, _ = s.markov_chain_calibrate(0, n_local, capi.calib_defaults(burn_in_iterations=a.burn_in))
         calibrated = int((status == 0).sum())
     acc0 = s.get_state()
     waves, lds = s.geometry
@@ -178,19 +198,21 @@ def main():
     steps_per_launch = (a.steps * R * n_swap * n_local) / max(launches.value, 1)
     achieved_gbs = bytes_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9
     flops_per_step = {"simplesin": 28.0, "sine3": 3 * 24.0 + 4}.get(w.name, 40.0) * w.n_data
-    # HBM bytes per launch from the PMC counters cannot be read inside this process; they are
-    # collected with `rocprofv3 --pmc` on this same command (profiles/README.md) and quoted here
-    # only when the workload is the one they were measured on
-    traffic = None
+    # HBM bytes per launch come from the PMC counters, which cannot be read inside this process:
+    # `traffic` stays null in this line; the figure profiled with `rocprofv3 --pmc` on this same
+    # command (profiles/README.md) is quoted as `traffic_profiled` when the workload is the one it
+    # was measured on
+    traffic_profiled = None
     key = "%s/%d/%d/%d/%d/%s" % (w.name, n_local, w.n_data, n_swap, R, "nosamples" if a.no_samples else "samples")
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        if pmc.get("workload_key") == key and world == 1:
-            traffic = pmc["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+        for pmc in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
+            if pmc.get("workload_key") == key and world == 1:
+                traffic_profiled = pmc["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError, TypeError):
         pass
     out = {
         "metric": "MCMC steps/sec (all chains) on %s, 1/2/4/8 MI355X + HBM-roofline %%" % w.name,
+        "baseline_config": a.config,
         "value": value, "unit": "Metropolis steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -202,8 +224,12 @@ def main():
                    "waves_per_chain": waves, "data_in_lds": lds, "parallelism": "ladder-sharded x%d" % world,
                    "edge_exchanges_rank0": ladder.exchanges,
                    "device_calibrated_chains_rank0": calibrated, "acceptance_rate_rank0": acceptance},
+        # `bound: hbm` is the nominal roofline of SURVEY 8(d) (algorithmic bytes: every step streams the
+        # data vector once); the data vector is LDS/L2-resident by design, so what actually limits the
+        # kernel is fp64 issue + the serial accept chain: see `limited_by` and `fp64_valu_frac`
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": traffic_profiled,
+                     "limited_by": "fp64 issue / dependent-operation latency (data vector resident in LDS or L2)",
                      "kernel": "pt_round_kernel", "launch_us": launch_ms * 1e3,
                      "algorithmic_bytes_per_launch": bytes_per_step * steps_per_launch,
                      "fp64_valu_frac": flops_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e12

@@ -75,6 +75,17 @@ enum {
 
 typedef struct apemost_hip_sampler apemost_hip_sampler;
 
+/* apemost_hip_config.flags */
+enum {
+    /* one round per launch: every swap attempt is the fused swap-in at the start of the next
+     * launch; no workgroup ever waits for another one (the fallback the engine also takes by
+     * itself when the grid cannot be co-resident, or after a failed in-launch hand-off) */
+    APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES = 1,
+    /* multi-round launches go through hipLaunchCooperativeKernel: the runtime guarantees (or
+     * refuses) co-residency of the whole grid instead of the engine's occupancy estimate */
+    APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH = 2
+};
+
 typedef struct {
     int32_t abi_version;     /* APEMOST_HIP_ABI_VERSION */
     int32_t device;          /* HIP device ordinal */
@@ -85,7 +96,7 @@ typedef struct {
     int32_t n_cols;          /* m->data->size2 (>= 2) */
     int32_t waves_per_chain; /* likelihood wavefronts per chain: 1, 2, 4, 6 or 8; 0 = choose */
     int32_t lds_policy;      /* data vector staged in LDS: 0 = choose, 1 = always (if it fits), 2 = never */
-    int32_t reserved;        /* must be 0 */
+    int32_t flags;           /* APEMOST_HIP_FLAG_* bits, 0 = defaults */
     int64_t chain_offset;    /* ladder index of local chain 0 */
     int64_t n_chains_global; /* N_BETA, src/define_defaults.h:24-31 */
     uint64_t seed;           /* rocRAND Philox4x32-10 seed (role of GSL_RNG_SEED) */

@@ -309,6 +309,11 @@ def step_for(ladder, rng, chain, p):
     lib().orc_markov_chain_step_for(C.byref(st), C.byref(rng.c), chain, p)
 
 
+def check_best(ladder, chain):
+    st = ladder.c_state()
+    lib().orc_check_best(C.byref(st), chain)
+
+
 def calc_model(ladder, chain):
     st = ladder.c_state()
     lib().orc_calc_model(C.byref(st), chain)

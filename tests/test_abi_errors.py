@@ -10,7 +10,7 @@ from apemost_amd import build, capi, workloads as wl
 
 def _cfg(**kw):
     base = dict(abi_version=capi.ABI_VERSION, device=0, model=wl.MODEL_SIMPLESIN, n_par=4, n_chains=4, n_data=16,
-                n_cols=2, waves_per_chain=0, lds_policy=0, reserved=0, chain_offset=0, n_chains_global=4, seed=1,
+                n_cols=2, waves_per_chain=0, lds_policy=0, flags=0, chain_offset=0, n_chains_global=4, seed=1,
                 sigma=0.5, hmin=1e-6)
     base.update(kw)
     return capi.Config(**base)

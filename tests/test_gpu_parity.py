@@ -185,24 +185,6 @@ def test_full_size_config2_properties():
     assert_match(a, lad, rng, what="config2")
 
 
-@pytest.mark.parametrize("name", ["simplesin", "pulse"])
-def test_calibration_matches_oracle(name):
-    w = small_workloads()[name]
-    n_chain = 4
-    st, lad, rng = make_pair(w, n_chain, seed=5, init_prob=True)
-    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=5, waves_per_chain=2)
-    s.set_state(st)
-    dcfg = capi.calib_defaults(burn_in_iterations=600, iter_limit=20000)
-    ocfg = orc.calib_defaults(burn_in_iterations=600, iter_limit=20000)
-    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
-    dev = s.get_state()
-    for c in range(n_chain):
-        st_o, it_o = orc.markov_chain_calibrate(lad, rng, c, ocfg)
-        assert status[c] == st_o and iters[c] == it_o, (c, status[c], st_o, iters[c], it_o)
-    assert_match(dev, lad, rng, what="calibrate " + name)
-    s.close()
-
-
 @pytest.mark.parametrize("split", [4, 3])
 def test_two_device_shards_equal_whole_ladder(split):
     """edge_export / edge_import / halo swap-in on the device: a ladder cut into two shards (both on
@@ -272,6 +254,61 @@ def test_sharded_driver_on_one_gpu_batches_rounds_and_matches_oracle():
     assert_match(dev, lad, rng, what="batched rounds")
     np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
     assert dev.swapcount.sum() > 10
+    s.close()
+
+
+@pytest.mark.parametrize("n_chain,n_data,flags", [(32, 128, capi.FLAG_SINGLE_ROUND_LAUNCHES), (4096, 64, 0),
+                                                  (32, 128, capi.FLAG_COOPERATIVE_LAUNCH)])
+def test_launch_policies_match_oracle(n_chain, n_data, flags):
+    """The three ways a run is cut into launches give the oracle's chain: (i) one round per launch
+    forced by flag -- every swap is the fused swap-in at launch start; (ii) the same fallback taken
+    by the engine itself because 4096 workgroups cannot be co-resident; (iii) multi-round launches
+    placed by hipLaunchCooperativeKernel."""
+    torch = _torch()
+    from apemost_amd.distributed import HipShardEngine, ShardedLadder
+    w = wl.simplesin(n_data=n_data, n_chain=n_chain)
+    n_rounds, n_swap, seed = (150, 4, 77) if n_chain < 100 else (12, 2, 78)
+    st, lad, rng = make_pair(w, n_chain, seed=seed)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=seed, flags=flags)
+    s.set_state(st)
+    if flags == capi.FLAG_COOPERATIVE_LAUNCH:
+        assert s.max_rounds_per_launch > 1
+    else:
+        assert s.max_rounds_per_launch == 1
+    d = torch.zeros((n_rounds, n_swap, n_chain, 6), dtype=torch.float64, device="cuda")
+    if n_chain < 100:
+        ladder = ShardedLadder(HipShardEngine(s, torch), n_chain, 0, n_chain, 0, 1, None)
+        ladder.run_sampler(n_rounds, n_swap, d)
+    else:
+        s.run_sampler(n_rounds, n_swap, d.data_ptr())
+    s.synchronize()
+    dev = s.get_state()
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True, n_threads=8)
+    assert_match(dev, lad, rng, what="launch policy")
+    np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+    assert dev.swapcount.sum() > (10 if n_chain < 100 else 0)
+    s.close()
+
+
+def test_impossible_prior_box_is_refused_not_spun_on():
+    """min > max can never be hit by the redraw loop (src/markov_chain.c:235-240 would spin on the
+    host, a kernel on the GPU): set_state refuses it"""
+    w = small_workloads()["simplesin"]
+    st, _, _ = make_pair(w, 4)
+    s = HipSampler(w.model, 4, 4, w.data)
+    s.set_state(st)
+    bad = st.copy()
+    bad.pmin[2, 1], bad.pmax[2, 1] = 1.0, 0.5
+    with pytest.raises(capi.ApemostHipError, match="chain 2 parameter 1"):
+        s.set_state(bad)
+    with pytest.raises(capi.ApemostHipError, match="min"):
+        s.set_state(bad, ("pmin",))          # one-sided view is checked against what the device holds
+    bad.pmax[0, 0] = np.nan
+    with pytest.raises(capi.ApemostHipError):
+        s.set_state(bad, ("pmax",))
+    s.run_sampler(3, 2)                      # the sampler still holds the good state
+    s.synchronize()
+    assert np.all(s.get_state().ticks == 6)
     s.close()
 
 

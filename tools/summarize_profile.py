@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Condenses the raw rocprofv3 output of tools/profile_config.sh (gpurun_out/<tag>/) into the small
+files kept under profiles/: <tag>_kernel_stats.csv (the --stats summary as rocprofv3 wrote it) and
+<tag>_counters.json (per-launch medians of the dominant kernel: HBM bytes with the gfx950
+correction of MI355X_MICROARCH.md, SQ counters and the ratios read from them)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter_rows(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    return rows
+
+
+def dominant(rows):
+    """the kernel with the largest total duration among pt_* kernels"""
+    tot = {}
+    for r in rows:
+        k = r["Kernel_Name"]
+        if "pt_round_kernel" in k:
+            tot[k] = tot.get(k, 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return max(tot, key=tot.get) if tot else None
+
+
+def per_launch(rows, kernel, min_us=0.0):
+    """counter -> list of per-dispatch values (dispatches of `kernel`; the 0-step finalise launches
+    are dropped by duration)"""
+    by = {}
+    durs = {}
+    for r in rows:
+        if r["Kernel_Name"] != kernel:
+            continue
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        durs[r["Dispatch_Id"]] = d
+        by.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+        by[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    if not durs:
+        return {}, 0.0, 0
+    med = statistics.median(durs.values())
+    keep = {i for i, d in durs.items() if d >= 0.5 * med}
+    out = {c: [v for i, v in vals.items() if i in keep] for c, vals in by.items()}
+    return out, statistics.median([durs[i] for i in keep]), len(keep)
+
+
+def main():
+    tag, cfg = sys.argv[1], sys.argv[2]
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    out = {"config": int(cfg), "tag": tag,
+           "command": "tools/profile_config.sh %s %s  (rocprofv3 ... -- python3 bench.py --config %s --cpu-seconds 0 --steps 10 --warmup 2)" % (cfg, tag, cfg)}
+    try:
+        out["bench_line"] = json.loads(open(os.path.join(src, "bench_short.json")).read().strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError):
+        pass
+    kernel = None
+    for name in ("sq", "fetch", "write"):
+        rows = counter_rows(os.path.join(src, name))
+        if not rows:
+            continue
+        kernel = kernel or dominant(rows)
+        vals, med_us, n = per_launch(rows, kernel)
+        out.setdefault("kernel", kernel)
+        out[name] = {"launches": n, "median_launch_us": med_us,
+                     "median": {c: statistics.median(v) for c, v in vals.items() if v}}
+        r0 = next((r for r in rows if r["Kernel_Name"] == kernel), None)
+        if r0:
+            out["registers"] = {"vgpr": int(r0["VGPR_Count"]), "agpr": int(r0["Accum_VGPR_Count"]),
+                                "sgpr": int(r0["SGPR_Count"]), "lds_bytes": int(r0["LDS_Block_Size"]),
+                                "scratch": int(r0["Scratch_Size"]), "workgroup": int(r0["Workgroup_Size"]),
+                                "grid": int(r0["Grid_Size"])}
+    f = out.get("fetch", {}).get("median", {}).get("FETCH_SIZE")
+    w = out.get("write", {}).get("median", {}).get("WRITE_SIZE")
+    if f is not None and w is not None:
+        # FETCH_SIZE/WRITE_SIZE are in KB; gfx950 tallies wide coalesced reads at half their bytes
+        out["hbm_bytes_per_launch"] = (2 * f + w) * 1024
+        out["hbm_correction"] = "FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B), WRITE_SIZE exact; KB -> bytes"
+    sq = out.get("sq", {}).get("median", {})
+    if sq:
+        wc = sq.get("SQ_WAVE_CYCLES", 0)
+        out["sq_ratios"] = {
+            "valu_active_share_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc if wc else None,
+            "issue_stall_share_of_wave_cycles": sq.get("SQ_WAIT_INST_ANY", 0) / wc if wc else None,
+            "parked_share_of_wave_cycles (s_waitcnt/barrier)": sq.get("SQ_WAIT_ANY", 0) / wc if wc else None,
+            "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
+            "lds_insts_per_wave": sq.get("SQ_INSTS_LDS", 0) / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
+            "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, summed over all waves",
+        }
+    with open(os.path.join(dst, tag + "_counters.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps({k: out[k] for k in ("kernel", "registers", "hbm_bytes_per_launch", "sq_ratios") if k in out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
