@@ -56,8 +56,10 @@ EXPORTS = [
     "apemost_hip_get_state", "apemost_hip_set_round", "apemost_hip_get_round", "apemost_hip_calc_model",
     "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_launch_rounds", "apemost_hip_max_rounds_per_launch",
     "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
-    "apemost_hip_samples_read", "apemost_hip_samples_free", "apemost_hip_swap_pair",
+    "apemost_hip_samples_read", "apemost_hip_samples_free", "apemost_hip_samples_read_async",
+    "apemost_hip_samples_wait", "apemost_hip_host_alloc", "apemost_hip_host_free", "apemost_hip_swap_pair",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
+    "apemost_hip_edge_exchange", "apemost_hip_run_shards",
     "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_rng_raw",
     "apemost_hip_rng_attempts", "apemost_hip_timer_begin", "apemost_hip_timer_end",
 ]
@@ -107,12 +109,21 @@ def lib():
     L.apemost_hip_launch_rounds.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp]
     L.apemost_hip_max_rounds_per_launch.argtypes = [vp, C.POINTER(C.c_int32)]
     L.apemost_hip_run.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
+    L.apemost_hip_samples_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.apemost_hip_samples_read.argtypes = [vp, vp, C.c_uint64, _dp]
+    L.apemost_hip_samples_free.argtypes = [vp, vp]
+    L.apemost_hip_samples_read_async.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    L.apemost_hip_samples_wait.argtypes = [vp]
+    L.apemost_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.apemost_hip_host_free.argtypes = [vp]
     L.apemost_hip_swap_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]
     L.apemost_hip_swap_pair.restype = C.c_int64
     L.apemost_hip_edge_doubles.argtypes = [C.c_int32]
     L.apemost_hip_edge_doubles.restype = C.c_int32
     L.apemost_hip_edge_export.argtypes = [vp, C.c_int, vp]
     L.apemost_hip_edge_import.argtypes = [vp, C.c_int, vp]
+    L.apemost_hip_edge_exchange.argtypes = [vp, vp]
+    L.apemost_hip_run_shards.argtypes = [C.POINTER(vp), C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(vp)]
     L.apemost_hip_calib_defaults.argtypes = [C.POINTER(CalibConfig)]
     L.apemost_hip_calib_defaults.restype = None
     L.apemost_hip_calibrate_chains.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(CalibConfig), C.c_int,

@@ -669,6 +669,11 @@ struct apemost_hip_sampler {
     int *d_status;
     u64 *d_iters;
     int calib_capacity;
+    double *edge_out, *edge_in;  // edge records for in-process shard exchanges (created on first use)
+    hipEvent_t ev_exported, ev_imported;
+    hipStream_t copy_stream; // drains sample rows while the next launch runs (created on first use)
+    hipEvent_t ev_copy;
+    u64 *h_word;             // pinned copy of the launch error word, refreshed by every async read
     bool cooperative;    // multi-round launches through hipLaunchCooperativeKernel
     bool handoff_failed; // an in-launch hand-off timed out once: single-round launches from then on
 };
@@ -763,6 +768,18 @@ static void release(apemost_hip_sampler *s) {
         hipFree(s->d_status);
     if (s->d_iters)
         hipFree(s->d_iters);
+    if (s->copy_stream) {
+        hipStreamSynchronize(s->copy_stream);
+        hipStreamDestroy(s->copy_stream);
+    }
+    if (s->ev_copy)
+        hipEventDestroy(s->ev_copy);
+    if (s->ev_exported)
+        hipEventDestroy(s->ev_exported);
+    if (s->ev_imported)
+        hipEventDestroy(s->ev_imported);
+    if (s->h_word)
+        hipHostFree(s->h_word);
     if (s->ev0)
         hipEventDestroy(s->ev0);
     if (s->ev1)
@@ -896,6 +913,11 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->calib_capacity = 0;
     s->stream = nullptr;
     s->ev0 = s->ev1 = nullptr;
+    s->copy_stream = nullptr;
+    s->ev_copy = nullptr;
+    s->edge_out = s->edge_in = nullptr;
+    s->ev_exported = s->ev_imported = nullptr;
+    s->h_word = nullptr;
     s->handoff_failed = false;
     s->waves = choose_waves(*cfg);
     rc = create_body(s);
@@ -1473,6 +1495,53 @@ extern "C" int apemost_hip_samples_read(apemost_hip_sampler *s, const double *d_
     return check_handoff(s); // rows of a void launch are not handed to the caller as samples
 }
 
+extern "C" int apemost_hip_samples_read_async(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
+                                              double *host_samples, uint64_t *counters) {
+    CHECK_S(s);
+    if (!d_samples || !host_samples)
+        return fail(APEMOST_HIP_ERR_INVALID, "samples_read_async: bad arguments");
+    if (!s->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_copy, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **)&s->h_word, sizeof(u64), hipHostMallocDefault));
+        *s->h_word = 0;
+    }
+    const size_t n = s->cfg.n_chains;
+    // small things ride on the sampler's own stream, in launch order: the counters as they stand now
+    // and the error word of the launches so far
+    if (counters)
+        HIP_TRY(hipMemcpyAsync(counters, s->d.accept(), 2 * n * sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_word, s->d.timeout_word(), sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->ev_copy, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_copy, 0));
+    const size_t bytes = (size_t)n_steps * n * (s->cfg.n_par + 2) * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(host_samples, d_samples, bytes, hipMemcpyDeviceToHost, s->copy_stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_samples_wait(apemost_hip_sampler *s) {
+    CHECK_S(s);
+    if (!s->copy_stream)
+        return APEMOST_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    if (*s->h_word != 0)
+        return apemost_hip_synchronize(s); // reports, clears and falls back (check_handoff)
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_host_alloc(size_t bytes, void **p) {
+    if (!p || bytes == 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "host_alloc: bad arguments");
+    HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_host_free(void *p) {
+    if (p)
+        HIP_TRY(hipHostFree(p));
+    return APEMOST_HIP_OK;
+}
+
 extern "C" int apemost_hip_samples_free(apemost_hip_sampler *s, double *d_samples) {
     CHECK_S(s);
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1530,6 +1599,112 @@ extern "C" int apemost_hip_edge_import(apemost_hip_sampler *s, int side, const d
     hipLaunchKernelGGL(edge_import_kernel, dim3(1), dim3(kWave), 0, s->stream, s->d, s->cfg.n_par, s->cur, row,
                        d_buf);
     HIP_TRY(hipGetLastError());
+    return APEMOST_HIP_OK;
+}
+
+static int edge_buffers(apemost_hip_sampler *s) {
+    if (s->edge_out)
+        return APEMOST_HIP_OK;
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    const size_t n = (size_t)apemost_hip_edge_doubles(s->cfg.n_par);
+    int rc;
+    if ((rc = dev_alloc(s, &s->edge_out, n)) || (rc = dev_alloc(s, &s->edge_in, n)))
+        return rc;
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_exported, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_imported, hipEventDisableTiming));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    // recorded once so that the first exchange has something to wait on
+    HIP_TRY(hipEventRecord(s->ev_exported, s->stream));
+    HIP_TRY(hipEventRecord(s->ev_imported, s->stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_edge_exchange(apemost_hip_sampler *lower, apemost_hip_sampler *upper) {
+    if (!lower || !upper || lower == upper)
+        return fail(APEMOST_HIP_ERR_INVALID, "edge_exchange: two different samplers are needed");
+    if (lower->cfg.n_par != upper->cfg.n_par || lower->cfg.n_chains_global != upper->cfg.n_chains_global ||
+        lower->cfg.seed != upper->cfg.seed ||
+        lower->cfg.chain_offset + lower->cfg.n_chains != upper->cfg.chain_offset)
+        return fail(APEMOST_HIP_ERR_INVALID, "edge_exchange: the shards are not neighbours of one ladder");
+    int rc;
+    if ((rc = edge_buffers(lower)) || (rc = edge_buffers(upper)))
+        return rc;
+    const size_t bytes = (size_t)apemost_hip_edge_doubles(lower->cfg.n_par) * sizeof(double);
+    apemost_hip_sampler *side[2] = {lower, upper};
+    // 1. each shard packs its edge chain, once its neighbour has finished reading the previous record
+    for (int k = 0; k < 2; k++) {
+        apemost_hip_sampler *me = side[k], *other = side[k ^ 1];
+        HIP_TRY(hipSetDevice(me->cfg.device));
+        HIP_TRY(hipStreamWaitEvent(me->stream, other->ev_imported, 0));
+        if ((rc = apemost_hip_edge_export(me, k == 0 ? 1 : 0, me->edge_out)))
+            return rc;
+        HIP_TRY(hipEventRecord(me->ev_exported, me->stream));
+    }
+    // 2. each shard pulls the neighbour's record into its halo row
+    for (int k = 0; k < 2; k++) {
+        apemost_hip_sampler *me = side[k], *other = side[k ^ 1];
+        HIP_TRY(hipSetDevice(me->cfg.device));
+        HIP_TRY(hipStreamWaitEvent(me->stream, other->ev_exported, 0));
+        HIP_TRY(hipMemcpyPeerAsync(me->edge_in, me->cfg.device, other->edge_out, other->cfg.device, bytes, me->stream));
+        HIP_TRY(hipEventRecord(me->ev_imported, me->stream));
+        if ((rc = apemost_hip_edge_import(me, k == 0 ? 1 : 0, me->edge_in)))
+            return rc;
+    }
+    return APEMOST_HIP_OK;
+}
+
+// the shard pair (j, j+1) the swap attempt `index` straddles, or -1
+static int straddled_edge(apemost_hip_sampler **sh, int n_shards, u64 index) {
+    const int64_t a = apemost_hip_swap_pair(sh[0]->cfg.seed, index, sh[0]->cfg.n_chains_global);
+    for (int j = 0; a >= 0 && j + 1 < n_shards; j++)
+        if (a == sh[j]->cfg.chain_offset + sh[j]->cfg.n_chains - 1)
+            return j;
+    return -1;
+}
+
+extern "C" int apemost_hip_run_shards(apemost_hip_sampler **sh, int32_t n_shards, uint64_t n_rounds, uint32_t n_swap,
+                                      double **d_samples) {
+    if (!sh || n_shards < 1)
+        return fail(APEMOST_HIP_ERR_INVALID, "run_shards: no shards");
+    int64_t next = 0;
+    for (int j = 0; j < n_shards; j++) {
+        if (!sh[j] || sh[j]->cfg.chain_offset != next || sh[j]->cfg.n_chains_global != sh[0]->cfg.n_chains_global ||
+            sh[j]->cfg.seed != sh[0]->cfg.seed || sh[j]->round != sh[0]->round ||
+            sh[j]->swap_pending != sh[0]->swap_pending)
+            return fail(APEMOST_HIP_ERR_INVALID, "run_shards: shard %d does not continue the ladder (offset, seed, "
+                                                 "ladder size and swap position must agree)", j);
+        next += sh[j]->cfg.n_chains;
+    }
+    if (next != sh[0]->cfg.n_chains_global)
+        return fail(APEMOST_HIP_ERR_INVALID, "run_shards: the shards cover %lld of %lld chains", (long long)next,
+                    (long long)sh[0]->cfg.n_chains_global);
+    int rc;
+    for (uint64_t r = 0; r < n_rounds || (r == n_rounds && sh[0]->swap_pending);) {
+        const bool finalise = r == n_rounds; // the swap attempt that closes the last round
+        const int pending = sh[0]->swap_pending;
+        const u64 first_inside = sh[0]->round + (pending ? 1 : 0);
+        uint64_t limit = finalise || n_swap == 0 ? 1 : n_rounds - r;
+        for (int j = 0; j < n_shards; j++)
+            if ((uint64_t)max_rounds_per_launch(sh[j]) < limit)
+                limit = (uint64_t)max_rounds_per_launch(sh[j]);
+        uint64_t k = 1;
+        while (k < limit && straddled_edge(sh, n_shards, first_inside + k - 1) < 0)
+            k++;
+        if (pending) {
+            const int j = straddled_edge(sh, n_shards, sh[0]->round);
+            if (j >= 0 && (rc = apemost_hip_edge_exchange(sh[j], sh[j + 1])))
+                return rc;
+        }
+        for (int j = 0; j < n_shards; j++) {
+            const size_t row = (size_t)sh[j]->cfg.n_chains * (sh[j]->cfg.n_par + 2);
+            double *out = (d_samples && d_samples[j] && !finalise) ? d_samples[j] + r * n_swap * row : nullptr;
+            if ((rc = launch_round_impl(sh[j], (uint32_t)k, finalise ? 0 : n_swap, pending, -1, out)))
+                return rc;
+        }
+        if (finalise)
+            break;
+        r += k;
+    }
     return APEMOST_HIP_OK;
 }
 

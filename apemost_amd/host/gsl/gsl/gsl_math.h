@@ -17,6 +17,16 @@
 #define GSL_FAILURE (-1)
 #define GSL_EDOM 1
 #define GSL_EINVAL 4
+#define GSL_EFAILED 5
+#define GSL_ENOMEM 8
+/* report through gsl_error (prints and aborts by default), then return like GSL's macros */
+#define GSL_ERROR_VAL(reason, gsl_errno, value)                                                   \
+    do {                                                                                          \
+        gsl_error(reason, __FILE__, __LINE__, gsl_errno);                                         \
+        return value;                                                                             \
+    } while (0)
+#define GSL_ERROR(reason, gsl_errno) GSL_ERROR_VAL(reason, gsl_errno, gsl_errno)
+#define GSL_ERROR_NULL(reason, gsl_errno) GSL_ERROR_VAL(reason, gsl_errno, 0)
 #define GSL_POSINF (1.0 / 0.0 * 1.0)
 #define GSL_MAX(a, b) ((a) > (b) ? (a) : (b))
 #define GSL_MIN(a, b) ((a) < (b) ? (a) : (b))

@@ -20,6 +20,18 @@ void apemost_ladder_close(apemost_ladder *l);
 apemost_hip_sampler *apemost_ladder_sampler(apemost_ladder *l);
 /* cached one-chain twin used by the single-chain API (markov_chain_step & co) */
 apemost_ladder *apemost_single(mcmc *m);
+/* The engine's per-chain RNG address: which stream family the chain draws from (its position in
+ * the ladder) and how many Metropolis updates it has made.  Kept beside the chain objects, keyed
+ * by pointer, so that `mcmc` and `parallel_tempering_mcmc` keep the reference's layout.  A chain
+ * seen for the first time gets tick 0 and the next free ladder position (creation order, so runs
+ * are reproducible); setup_chains() assigns positions explicitly; mcmc_free() forgets the chain. */
+typedef struct {
+    unsigned long tick;     /* Metropolis updates performed so far */
+    unsigned long chain_id; /* position in the ladder */
+} apemost_chain_address_t;
+apemost_chain_address_t *apemost_chain_address(const mcmc *m);
+void apemost_chain_place(const mcmc *m, unsigned long chain_id); /* (re)register at a ladder position, tick 0 */
+void apemost_chain_forget(const mcmc *m);
 /* number of tempering_interaction() calls so far in this process */
 extern unsigned long apemost_swap_round;
 

@@ -15,14 +15,14 @@
 #endif
 #define BETA_0_STEPWIDTH 1.0
 
+/* exactly the reference's two fields (src/parallel_tempering_beta.h:65-76): applications allocate
+ * this struct themselves (mem_malloc(sizeof(parallel_tempering_mcmc)), apps/eval_main.c:50), so its
+ * size is part of the binary contract.  What the engine needs per chain beyond it -- the chain's
+ * address in the device RNG streams -- lives in a side table of the bridge, keyed by the mcmc
+ * pointer (apemost_bridge.h: apemost_chain_address). */
 typedef struct {
     double beta;             /* inverse temperature */
     unsigned long swapcount; /* accepted swaps with the next-hotter chain */
-    /* engine additions behind the reference's two fields (applications only ever take
-     * sizeof() of this struct and go through set_beta/get_beta): the chain's address in
-     * the device RNG streams */
-    unsigned long tick;      /* Metropolis updates performed so far */
-    unsigned long chain_id;  /* position in the ladder */
 } parallel_tempering_mcmc;
 
 void set_beta(mcmc *m, const double newbeta);

@@ -40,6 +40,83 @@ static unsigned long env_seed(void) {
 
 static parallel_tempering_mcmc *pt(const mcmc *m) { return (parallel_tempering_mcmc *)m->additional_data; }
 
+/* ---- side table: mcmc pointer -> RNG address (open addressing, linear probing, tombstones) ---- */
+struct address_slot {
+    const mcmc *key; /* NULL = never used, TOMBSTONE = forgotten */
+    apemost_chain_address_t a;
+};
+static struct address_slot *address_table = NULL;
+static size_t address_cap = 0, address_used = 0; /* used counts live keys and tombstones */
+static unsigned long address_next_id = 0;
+static const mcmc *const TOMBSTONE = (const mcmc *)&address_table;
+
+static size_t address_hash(const mcmc *m, size_t cap) {
+    size_t x = (size_t)m;
+    x ^= x >> 17;
+    x *= (size_t)0x9E3779B97F4A7C15ul;
+    x ^= x >> 29;
+    return x & (cap - 1);
+}
+
+static struct address_slot *address_find(const mcmc *m, int create) {
+    size_t i;
+    struct address_slot *grave = NULL;
+    if (address_cap == 0 || (create && 2 * (address_used + 1) > address_cap)) {
+        /* grow (or start): re-insert the live entries, dropping tombstones */
+        const size_t old_cap = address_cap, cap = old_cap ? 2 * old_cap : 64;
+        struct address_slot *old = address_table;
+        if (!create && old_cap == 0)
+            return NULL;
+        address_table = (struct address_slot *)calloc(cap, sizeof(struct address_slot));
+        address_cap = cap;
+        address_used = 0;
+        for (i = 0; i < old_cap; i++)
+            if (old[i].key != NULL && old[i].key != TOMBSTONE) {
+                size_t j = address_hash(old[i].key, cap);
+                while (address_table[j].key != NULL)
+                    j = (j + 1) & (cap - 1);
+                address_table[j] = old[i];
+                address_used++;
+            }
+        free(old);
+    }
+    for (i = address_hash(m, address_cap);; i = (i + 1) & (address_cap - 1)) {
+        struct address_slot *s = &address_table[i];
+        if (s->key == m)
+            return s;
+        if (s->key == TOMBSTONE && grave == NULL)
+            grave = s;
+        if (s->key == NULL) {
+            if (!create)
+                return NULL;
+            if (grave != NULL)
+                s = grave;
+            else
+                address_used++;
+            s->key = m;
+            s->a.tick = 0;
+            s->a.chain_id = address_next_id++;
+            return s;
+        }
+    }
+}
+
+apemost_chain_address_t *apemost_chain_address(const mcmc *m) { return &address_find(m, 1)->a; }
+
+void apemost_chain_place(const mcmc *m, unsigned long chain_id) {
+    apemost_chain_address_t *a = apemost_chain_address(m);
+    a->tick = 0;
+    a->chain_id = chain_id;
+    if (chain_id >= address_next_id)
+        address_next_id = chain_id + 1;
+}
+
+void apemost_chain_forget(const mcmc *m) {
+    struct address_slot *s = address_find(m, 0);
+    if (s != NULL)
+        s->key = TOMBSTONE;
+}
+
 /* -DCIRCULAR_PARAMS=1,2,...: 1-based indices of the parameters that wrap around their range
  * (reference src/markov_chain.h:34-46); the default single 0 means none */
 static uint64_t circular_mask(void) {
@@ -113,6 +190,7 @@ int apemost_detect_model(mcmc *m) {
         dev_prior[DETECT_POINTS];
     gsl_vector *saved;
     double saved_prob, saved_prior;
+    const double saved_beta = pt(m) ? pt(m)->beta : 1.0;
     unsigned int j, p;
     int model, found = -1;
 
@@ -132,11 +210,18 @@ int apemost_detect_model(mcmc *m) {
             pts[j * n + p] = lo + (hi - lo) * (0.05 + 0.9 * frac);
             gsl_vector_set(m->params, p, pts[j * n + p]);
         }
-        beta[j] = pt(m) ? get_beta(m) : 1.0;
+        /* every other point at a second temperature: a plugin that tempers differently from the
+         * device model (e.g. the library flavour's beta * (prior + loglike), quirk Q6) must not pass
+         * because the chain happens to sit at beta = 1 */
+        beta[j] = pt(m) ? ((j & 1) ? 0.37 * saved_beta : saved_beta) : 1.0;
+        if (pt(m))
+            pt(m)->beta = beta[j];
         calc_model(m, NULL);
         host_prob[j] = m->prob;
         host_prior[j] = m->prior;
     }
+    if (pt(m))
+        pt(m)->beta = saved_beta;
     gsl_vector_memcpy(m->params, saved);
     gsl_vector_free(saved);
     m->prob = saved_prob;
@@ -237,7 +322,7 @@ void apemost_ladder_upload(apemost_ladder *l) {
         }
         l->v.beta[c] = pt(m) ? pt(m)->beta : 1.0;
         l->v.swapcount[c] = pt(m) ? pt(m)->swapcount : 0;
-        l->v.ticks[c] = pt(m) ? pt(m)->tick : 0;
+        l->v.ticks[c] = apemost_chain_address(m)->tick;
         l->v.prob[c] = m->prob;
         l->v.prior[c] = m->prior;
         l->v.prob_best[c] = m->prob_best;
@@ -262,10 +347,9 @@ void apemost_ladder_download(apemost_ladder *l) {
             m->params_accepts[p] = (unsigned long)l->v.params_accepts[k];
             m->params_rejects[p] = (unsigned long)l->v.params_rejects[k];
         }
-        if (pt(m)) {
+        if (pt(m))
             pt(m)->swapcount = (unsigned long)l->v.swapcount[c];
-            pt(m)->tick = (unsigned long)l->v.ticks[c];
-        }
+        apemost_chain_address(m)->tick = (unsigned long)l->v.ticks[c];
         m->prob = l->v.prob[c];
         m->prior = l->v.prior[c];
         m->prob_best = l->v.prob_best[c];
@@ -316,7 +400,7 @@ apemost_ladder *apemost_single(mcmc *m) {
         cache_data = m->data;
     }
     slot[0] = m;
-    apemost_hip_or_die(apemost_hip_set_chain_offset(cache->s, pt(m) ? (long)(pt(m)->chain_id % SINGLE_LADDER_SPAN) : 0),
+    apemost_hip_or_die(apemost_hip_set_chain_offset(cache->s, (long)(apemost_chain_address(m)->chain_id % SINGLE_LADDER_SPAN)),
                        "apemost_hip_set_chain_offset");
     return cache;
 }

@@ -17,3 +17,20 @@ double calc_vector_sum(const gsl_vector *v) {
         s += gsl_vector_get(v, i);
     return s;
 }
+
+/* element-wise: a := max(a, b) / a := min(a, b) */
+void max_vector(gsl_vector *a, const gsl_vector *b) {
+    size_t i;
+    assert(a->size == b->size);
+    for (i = 0; a != b && i < a->size; i++)
+        if (gsl_vector_get(b, i) > gsl_vector_get(a, i))
+            gsl_vector_set(a, i, gsl_vector_get(b, i));
+}
+
+void min_vector(gsl_vector *a, const gsl_vector *b) {
+    size_t i;
+    assert(a->size == b->size);
+    for (i = 0; a != b && i < a->size; i++)
+        if (gsl_vector_get(b, i) < gsl_vector_get(a, i))
+            gsl_vector_set(a, i, gsl_vector_get(b, i));
+}

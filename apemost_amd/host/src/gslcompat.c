@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <gsl/gsl_matrix.h>
+#include <gsl/gsl_histogram.h>
+#include <math.h>
 #include <gsl/gsl_randist.h>
 #include <gsl/gsl_sf.h>
 
@@ -320,3 +322,126 @@ double gsl_sf_log(const double x) {
 double gsl_sf_sin(const double x) { return sin(x); }
 double gsl_sf_cos(const double x) { return cos(x); }
 double gsl_sf_exp(const double x) { return exp(x); }
+
+/* ---- histograms: bin i covers [range[i], range[i+1]) ---- */
+gsl_histogram *gsl_histogram_alloc(size_t n) {
+    gsl_histogram *h;
+    if (n == 0)
+        GSL_ERROR_NULL("histogram length n must be positive integer", GSL_EDOM);
+    h = (gsl_histogram *)malloc(sizeof(gsl_histogram));
+    h->range = h ? (double *)calloc(n + 1, sizeof(double)) : NULL;
+    h->bin = h ? (double *)calloc(n, sizeof(double)) : NULL;
+    if (h == NULL || h->range == NULL || h->bin == NULL)
+        GSL_ERROR_NULL("failed to allocate space for histogram", GSL_ENOMEM);
+    h->n = n;
+    return h;
+}
+
+void gsl_histogram_free(gsl_histogram *h) {
+    if (h == NULL)
+        return;
+    free(h->range);
+    free(h->bin);
+    free(h);
+}
+
+int gsl_histogram_set_ranges_uniform(gsl_histogram *h, double xmin, double xmax) {
+    const size_t n = h->n;
+    size_t i;
+    if (xmin >= xmax)
+        GSL_ERROR("xmin must be less than xmax", GSL_EINVAL);
+    for (i = 0; i <= n; i++) {
+        const double f1 = (double)(n - i) / (double)n, f2 = (double)i / (double)n;
+        h->range[i] = f1 * xmin + f2 * xmax;
+    }
+    for (i = 0; i < n; i++)
+        h->bin[i] = 0;
+    return GSL_SUCCESS;
+}
+
+int gsl_histogram_increment(gsl_histogram *h, double x) {
+    size_t lo = 0, hi = h->n;
+    if (!(x >= h->range[0]) || !(x < h->range[h->n]))
+        return GSL_EDOM; /* outside: silently ignored, as GSL does */
+    while (hi - lo > 1) { /* range[lo] <= x < range[hi] */
+        const size_t mid = (lo + hi) / 2;
+        if (x >= h->range[mid])
+            lo = mid;
+        else
+            hi = mid;
+    }
+    h->bin[lo] += 1;
+    return GSL_SUCCESS;
+}
+
+double gsl_histogram_get(const gsl_histogram *h, size_t i) {
+    if (i >= h->n)
+        GSL_ERROR_VAL("index lies outside valid range of 0 .. n - 1", GSL_EDOM, 0);
+    return h->bin[i];
+}
+
+int gsl_histogram_get_range(const gsl_histogram *h, size_t i, double *lower, double *upper) {
+    if (i >= h->n)
+        GSL_ERROR("index lies outside valid range of 0 .. n - 1", GSL_EDOM);
+    *lower = h->range[i];
+    *upper = h->range[i + 1];
+    return GSL_SUCCESS;
+}
+
+double gsl_histogram_max(const gsl_histogram *h) { return h->range[h->n]; }
+double gsl_histogram_min(const gsl_histogram *h) { return h->range[0]; }
+size_t gsl_histogram_bins(const gsl_histogram *h) { return h->n; }
+
+double gsl_histogram_sum(const gsl_histogram *h) {
+    double s = 0;
+    size_t i;
+    for (i = 0; i < h->n; i++)
+        s += h->bin[i];
+    return s;
+}
+
+/* weighted mean / spread of the bin centres (negative bins count as empty) */
+double gsl_histogram_mean(const gsl_histogram *h) {
+    double mean = 0, w = 0;
+    size_t i;
+    for (i = 0; i < h->n; i++) {
+        const double x = (h->range[i + 1] + h->range[i]) / 2, b = h->bin[i];
+        if (b > 0) {
+            w += b;
+            mean += (x - mean) * (b / w);
+        }
+    }
+    return mean;
+}
+
+double gsl_histogram_sigma(const gsl_histogram *h) {
+    const double mean = gsl_histogram_mean(h);
+    double var = 0, w = 0;
+    size_t i;
+    for (i = 0; i < h->n; i++) {
+        const double d = (h->range[i + 1] + h->range[i]) / 2 - mean, b = h->bin[i];
+        if (b > 0) {
+            w += b;
+            var += (d * d - var) * (b / w);
+        }
+    }
+    return sqrt(var);
+}
+
+int gsl_histogram_scale(gsl_histogram *h, double scale) {
+    size_t i;
+    for (i = 0; i < h->n; i++)
+        h->bin[i] *= scale;
+    return GSL_SUCCESS;
+}
+
+int gsl_histogram_fprintf(FILE *stream, const gsl_histogram *h, const char *range_format, const char *bin_format) {
+    size_t i;
+    for (i = 0; i < h->n; i++) {
+        if (fprintf(stream, range_format, h->range[i]) < 0 || putc(' ', stream) == EOF ||
+            fprintf(stream, range_format, h->range[i + 1]) < 0 || putc(' ', stream) == EOF ||
+            fprintf(stream, bin_format, h->bin[i]) < 0 || putc('\n', stream) == EOF)
+            GSL_ERROR("fprintf failed", GSL_EFAILED);
+    }
+    return GSL_SUCCESS;
+}

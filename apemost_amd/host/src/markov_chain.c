@@ -102,8 +102,10 @@ void markov_chain_calibrate(mcmc *m, const unsigned int burn_in_iterations, doub
     apemost_ladder_download(l);
 }
 
-/* adaptive random-walk Metropolis of the reference (:342-367) is behind -DRWM, which does
- * not compile there (SURVEY component 3); kept as host arithmetic on the step widths */
+/* Step-width adaptation of the reference's (non-default, there uncompilable) -DRWM variant,
+ * src/markov_chain.c:342-367: every width moves by a random fraction of its parameter range,
+ * towards wider steps when the last move was accepted more readily than TARGET_ACCEPTANCE_RATE,
+ * towards narrower ones otherwise; the pull fades as 1/sqrt(n_iter).  Host arithmetic only. */
 #ifndef MINIMAL_STEPWIDTH
 #define MINIMAL_STEPWIDTH 0.0000001
 #endif
@@ -111,34 +113,75 @@ void markov_chain_calibrate(mcmc *m, const unsigned int burn_in_iterations, doub
 #define MAXIMAL_STEPWIDTH 1000000
 #endif
 void rmw_adapt_stepwidth(mcmc *m, const double prob_old) {
-    unsigned int i;
-    double alpha = exp(get_prob(m) - prob_old);
-    if (alpha > 1)
-        alpha = 1;
-    for (i = 0; i < get_n_par(m); i++) {
-        const double scale = get_params_max_for(m, i) - get_params_min_for(m, i);
-        double step = get_steps_for(m, i);
-        step += get_next_uniform_random(m) / sqrt(m->n_iter) * (alpha - TARGET_ACCEPTANCE_RATE) * scale;
-        if (step < MINIMAL_STEPWIDTH * scale)
-            step = MINIMAL_STEPWIDTH * scale;
-        if (step > MAXIMAL_STEPWIDTH * scale)
-            step = MAXIMAL_STEPWIDTH * scale;
-        set_steps_for(m, step, i);
+    const double ratio = exp(get_prob(m) - prob_old);
+    const double pull = ((ratio < 1 ? ratio : 1) - TARGET_ACCEPTANCE_RATE) / sqrt(m->n_iter);
+    unsigned int p;
+    for (p = 0; p < get_n_par(m); p++) {
+        const double range = get_params_max_for(m, p) - get_params_min_for(m, p);
+        const double narrowest = MINIMAL_STEPWIDTH * range, widest = MAXIMAL_STEPWIDTH * range;
+        double width = get_steps_for(m, p) + get_next_uniform_random(m) * pull * range;
+        width = width < narrowest ? narrowest : width;
+        width = width > widest ? widest : width;
+        set_steps_for(m, width, p);
     }
 }
 
-/* only the alternate calibrators (-DCALIBRATE_*) use this; they are out of scope */
+/* assess_acceptance_rate (reference src/markov_chain.c:117-224; used by the alternate calibrators
+ * and by applications that tune widths themselves): measure the acceptance rate of parameter
+ * `param` (or of the all-parameter step when param >= n_par) to an accuracy that tightens as the
+ * rate approaches the desired one.  Every step is a device step (markov_chain_step[_for]).
+ *
+ * The estimate follows the reference to the letter, including two things a reader might not
+ * expect: the rate is (accepts before the LAST step of the batch) / n, and the drift of the
+ * running accept count around rate * j is truncated to an integer before it is compared.
+ * Returns the number of steps used. */
 unsigned int assess_acceptance_rate(mcmc *m, unsigned int param, double desired_acceptance_rate,
                                     double min_accuracy, double max_accuracy, double *acceptance_rate,
                                     double *accuracy) {
-    (void)m;
-    (void)param;
-    (void)desired_acceptance_rate;
-    (void)min_accuracy;
-    (void)max_accuracy;
-    (void)acceptance_rate;
-    (void)accuracy;
-    fprintf(stderr, "assess_acceptance_rate: alternate calibrators are not part of this engine.\n");
-    exit(1);
-    return 0;
+    const int single = param < get_n_par(m);
+    unsigned int done = 0, n = 40, j;
+    unsigned char *accepted = NULL; /* one flag per step, kept over all batches */
+    reset_accept_rejects(m);
+    for (;;) {
+        unsigned long before = 0, running = 0;
+        unsigned int drift = 1;
+        double rate, wanted;
+        accepted = (unsigned char *)realloc(accepted, n);
+        assert(accepted != NULL);
+        for (; done < n; done++) {
+            before = single ? get_params_accepts_for(m, param) : get_params_accepts_global(m);
+            if (single)
+                markov_chain_step_for(m, param);
+            else
+                markov_chain_step(m);
+            mcmc_check_best(m);
+            accepted[done] = before != (single ? get_params_accepts_for(m, param) : get_params_accepts_global(m));
+        }
+        rate = before / (double)n;
+        for (j = 0; j < n; j++) {
+            int off;
+            running += accepted[j];
+            off = (int)(running - rate * j);
+            if (off < 0)
+                off = -off;
+            if ((unsigned int)off > drift)
+                drift = (unsigned int)off;
+        }
+        wanted = (rate < desired_acceptance_rate ? desired_acceptance_rate - rate : rate - desired_acceptance_rate) *
+                 ACCURACY_DEVIATION_FACTOR;
+        if (wanted < 0.005)
+            wanted = 0.005;
+        if (wanted < min_accuracy)
+            wanted = min_accuracy;
+        if (wanted > max_accuracy)
+            wanted = max_accuracy;
+        *acceptance_rate = rate;
+        *accuracy = drift / 1. / n;
+        if (*accuracy <= wanted)
+            break;
+        assert(drift / wanted >= n);
+        n = ((unsigned int)((drift / 1. / wanted) / 8) + 1) * 8; /* enough steps for that drift to weigh `wanted` */
+    }
+    free(accepted);
+    return n;
 }

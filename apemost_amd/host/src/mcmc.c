@@ -4,6 +4,7 @@
 #include "mcmc.h"
 #include "mcmc_internal.h"
 #include "debug.h"
+#include "apemost_bridge.h"
 
 /* one host RNG shared by every chain of the process, created on first use */
 static gsl_rng *shared_rng = NULL;
@@ -45,6 +46,7 @@ mcmc *mcmc_init(const unsigned int n_pars) {
 
 mcmc *mcmc_free(mcmc *m) {
     unsigned int i;
+    apemost_chain_forget(m);
     mcmc_dump_close(m);
     if (shared_rng != NULL && m->random == shared_rng) {
         gsl_rng_free(shared_rng);

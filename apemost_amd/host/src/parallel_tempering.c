@@ -189,9 +189,169 @@ static unsigned long gcd_ul(unsigned long a, unsigned long b) {
     return a;
 }
 
-/* The sampler loop: batches of rounds on the device, then the batch's sample rows are
- * written in the reference's formats: <name>-chain-<i>.prob.dump (chain 0, or all with
- * -DDUMP_ALL_CHAINS), prob-chain<i>.dump, acceptance_rate.dump(.gnuplot), progress line. */
+/* ---- sample sink ------------------------------------------------------------------------
+ * Where the sample rows of the run phase go.  Selected at run time by APEMOST_DUMP, a comma
+ * separated list of
+ *   text     (default) the reference's files: <name>-chain-<i>.prob.dump ("%.15e", chain 0 or
+ *            all chains with -DDUMP_ALL_CHAINS; src/mcmc_dump.c:79-88) and prob-chain<i>.dump
+ *            ("%6e\t%6e" for every chain; src/parallel_tempering.c:399-401)
+ *   binary   one file samples.bin: a 64-byte header, then per kept step n_beta rows of n_par+2
+ *            doubles (params..., prob, prob - prior) exactly as the device wrote them
+ *            (tools/samples_bin.py reads it and can expand it into the text files)
+ *   thin:N   keep every N-th iteration only (either format)
+ * The reference prints one line per chain per step, which at device speed is the whole run time
+ * (SURVEY 8 f1); binary and thinned sinks are the additive options for that. */
+#define SINK_MAGIC "APEMOSTB"
+#ifndef PROB_FILES_OPEN_MAX
+#define PROB_FILES_OPEN_MAX 256 /* beyond this many chains prob-chain files are opened per batch */
+#endif
+
+typedef struct {
+    int binary;
+    unsigned long thin;
+    unsigned int n_beta, n_par;
+    const char *mode;  /* "w" or "a" */
+    FILE *bin;         /* binary sink */
+    FILE **prob_files; /* text sink, ladders up to PROB_FILES_OPEN_MAX chains: kept open */
+    int batches;       /* batches written so far (pooled text files switch to append after the first) */
+} sample_sink;
+
+static void sink_parse(sample_sink *k) {
+    const char *spec = getenv("APEMOST_DUMP");
+    k->binary = 0;
+    k->thin = 1;
+    while (spec != NULL && *spec != 0) {
+        if (strncmp(spec, "binary", 6) == 0)
+            k->binary = 1;
+        else if (strncmp(spec, "text", 4) == 0)
+            k->binary = 0;
+        else if (strncmp(spec, "thin:", 5) == 0 && atol(spec + 5) > 0)
+            k->thin = (unsigned long)atol(spec + 5);
+        else {
+            fprintf(stderr, "APEMOST_DUMP: expected a comma separated list of text, binary, thin:N; got '%s'\n", spec);
+            exit(1);
+        }
+        spec = strchr(spec, ',');
+        if (spec != NULL)
+            spec++;
+    }
+}
+
+static FILE *open_or_die(const char *name, const char *mode) {
+    FILE *f = fopen(name, mode);
+    if (f == NULL) {
+        fprintf(stderr, "opening file %s failed\n", name);
+        perror("opening file failed");
+        exit(1);
+    }
+    return f;
+}
+
+static void sink_open(sample_sink *k, unsigned int n_beta, unsigned int n_par, unsigned int n_swap, const char *mode) {
+    unsigned int i;
+    char name[100];
+    sink_parse(k);
+    k->n_beta = n_beta;
+    k->n_par = n_par;
+    k->mode = mode;
+    k->bin = NULL;
+    k->prob_files = NULL;
+    k->batches = 0;
+    if (k->binary) {
+        unsigned char header[64];
+        uint32_t u32[4];
+        uint64_t u64v = k->thin;
+        const int fresh = mode[0] == 'w' || fopen("samples.bin", "rb") == NULL;
+        k->bin = open_or_die("samples.bin", fresh ? "wb" : "ab");
+        if (fresh) {
+            memset(header, 0, sizeof header);
+            memcpy(header, SINK_MAGIC, 8);
+            u32[0] = 1; /* format version */
+            u32[1] = n_beta;
+            u32[2] = n_par;
+            u32[3] = n_swap;
+            memcpy(header + 8, u32, sizeof u32);
+            memcpy(header + 24, &u64v, sizeof u64v);
+            fwrite(header, 1, sizeof header, k->bin);
+        }
+        return;
+    }
+    if (n_beta <= PROB_FILES_OPEN_MAX) {
+        k->prob_files = (FILE **)mem_calloc(n_beta, sizeof(FILE *));
+        for (i = 0; i < n_beta; i++) {
+            sprintf(name, "prob-chain%d.dump", i);
+            k->prob_files[i] = open_or_die(name, mode);
+        }
+    }
+}
+
+/* rows of iterations first+1 .. first+n_steps; h = [n_steps][n_beta][n_par+2] */
+static void sink_write(sample_sink *k, mcmc **chains, const double *h, unsigned long first, unsigned long n_steps) {
+    const unsigned int n_beta = k->n_beta, n_par = k->n_par;
+    const size_t row = (size_t)n_beta * (n_par + 2);
+    /* first kept step of this batch: iteration numbers count from 1 */
+    const unsigned long skip = (k->thin - (first % k->thin) - 1) % k->thin;
+    unsigned long step;
+    unsigned int i, p;
+    char name[100];
+    if (k->binary) {
+        if (k->thin == 1)
+            fwrite(h, sizeof(double), n_steps * row, k->bin);
+        else
+            for (step = skip; step < n_steps; step += k->thin)
+                fwrite(h + step * row, sizeof(double), row, k->bin);
+        k->batches++;
+        return;
+    }
+    /* chain-major: one file at a time stays hot, and ladders beyond the descriptor limit
+     * (the reference asserts n_beta < 100) open, append to and close one prob file at a time */
+    for (i = 0; i < n_beta; i++) {
+        FILE *pf = k->prob_files ? k->prob_files[i] : NULL;
+        FILE **vf = chains[i]->files;
+        if (pf == NULL) {
+            sprintf(name, "prob-chain%d.dump", i);
+            pf = open_or_die(name, k->batches == 0 ? k->mode : "a");
+        }
+        for (step = skip; step < n_steps; step += k->thin) {
+            const double *r = h + step * row + (size_t)i * (n_par + 2);
+            if (vf != NULL)
+                for (p = 0; p < n_par; p++)
+                    if (vf[p] != NULL)
+                        fprintf(vf[p], DUMP_FORMAT "\n", r[p]);
+            fprintf(pf, "%6e\t%6e\n", r[n_par], r[n_par + 1]);
+        }
+        if (k->prob_files == NULL)
+            fclose(pf);
+    }
+    k->batches++;
+}
+
+static void sink_flush(sample_sink *k) {
+    unsigned int i;
+    if (k->bin)
+        fflush(k->bin);
+    if (k->prob_files)
+        for (i = 0; i < k->n_beta; i++)
+            fflush(k->prob_files[i]);
+}
+
+static void sink_close(sample_sink *k) {
+    unsigned int i;
+    if (k->bin)
+        fclose(k->bin);
+    if (k->prob_files) {
+        for (i = 0; i < k->n_beta; i++)
+            fclose(k->prob_files[i]);
+        mem_free(k->prob_files);
+    }
+}
+
+/* The sampler loop.  The device runs batches of rounds (apemost_hip_run: n_swap steps per chain,
+ * one swap attempt, ... -- the body of the reference's loop, src/parallel_tempering.c:392-409);
+ * while batch k+1 runs, the rows of batch k drain into pinned host memory on a second stream and
+ * are written by the sink.  Batches end at the iterations where the reference prints its
+ * acceptance line (src/parallel_tempering.c:320-326, 405-407); the accept counters for that line are
+ * snapshotted in stream order together with the rows, so the loop never stalls the device. */
 static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned int n_swap,
                         const unsigned long max_iterations, char *mode) {
     const unsigned int n_par = get_n_par(chains[0]);
@@ -200,27 +360,21 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
     /* rounds between two acceptance lines; batches never cross such a point */
     const unsigned long interval_rounds = PRINT_PROB_INTERVAL / gcd_ul(PRINT_PROB_INTERVAL, n_swap);
     unsigned long max_rounds = (unsigned long)(((size_t)64 << 20) / (row * n_swap * sizeof(double)));
-    FILE **prob_files = (FILE **)mem_calloc(n_beta, sizeof(FILE *));
+    unsigned long rounds_now, rounds_next;
+    sample_sink sink;
     FILE *acceptance_file;
     apemost_ladder *l;
     apemost_hip_sampler *s;
-    double *d_samples = NULL, *h_samples;
-    char name[100];
-    unsigned int i, p;
+    double *d_samples[2] = {NULL, NULL}, *h_samples[2] = {NULL, NULL};
+    uint64_t *h_counts[2] = {NULL, NULL};
+    unsigned int i;
+    int k = 0;
 
     if (max_rounds < 1)
         max_rounds = 1;
     if (max_rounds > interval_rounds)
         max_rounds = interval_rounds;
-    for (i = 0; i < n_beta; i++) {
-        sprintf(name, "prob-chain%d.dump", i);
-        prob_files[i] = fopen(name, mode);
-        if (prob_files[i] == NULL) {
-            fprintf(stderr, "opening file %s failed\n", name);
-            perror("opening file failed");
-            exit(1);
-        }
-    }
+    sink_open(&sink, n_beta, n_par, n_swap, mode);
     acceptance_file = fopen("acceptance_rate.dump.gnuplot", "w");
     if (acceptance_file != NULL) {
         fprintf(acceptance_file, "# format: iteration | number of accepts for each chain\nplot ");
@@ -230,74 +384,88 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
         fprintf(acceptance_file, "\n");
         fclose(acceptance_file);
     }
-    acceptance_file = fopen("acceptance_rate.dump", mode);
-    assert(acceptance_file != NULL);
+    acceptance_file = open_or_die("acceptance_rate.dump", mode);
 
     l = apemost_ladder_open(chains, n_beta);
     s = apemost_ladder_sampler(l);
-    apemost_hip_or_die(apemost_hip_samples_alloc(s, max_rounds * n_swap, &d_samples), "samples_alloc");
-    h_samples = (double *)malloc(max_rounds * n_swap * row * sizeof(double));
-    assert(h_samples != NULL);
+    for (i = 0; i < 2; i++) {
+        void *p = NULL;
+        apemost_hip_or_die(apemost_hip_samples_alloc(s, max_rounds * n_swap, &d_samples[i]), "samples_alloc");
+        apemost_hip_or_die(apemost_hip_host_alloc(max_rounds * n_swap * row * sizeof(double), &p), "host_alloc");
+        h_samples[i] = (double *)p;
+        apemost_hip_or_die(apemost_hip_host_alloc(2 * (size_t)n_beta * sizeof(uint64_t), &p), "host_alloc");
+        h_counts[i] = (uint64_t *)p;
+    }
     get_duration();
     run = 1;
     dumpflag = 0;
     printf("starting the analysis\n");
     fflush(stdout);
 
-    while (run && (max_iterations == 0 || iter < max_iterations)) {
-        const unsigned long done_rounds = iter / n_swap;
-        unsigned long rounds = interval_rounds - done_rounds % interval_rounds, step;
-        if (rounds > max_rounds)
-            rounds = max_rounds;
-        if (max_iterations != 0) {
-            const unsigned long left = (max_iterations - iter + n_swap - 1) / n_swap;
-            if (rounds > left)
-                rounds = left;
-        }
-        apemost_hip_or_die(apemost_hip_run(s, rounds, n_swap, d_samples), "run_sampler");
-        apemost_hip_or_die(apemost_hip_samples_read(s, d_samples, rounds * n_swap, h_samples), "samples_read");
-        for (step = 0; step < rounds * n_swap; step++) {
-            for (i = 0; i < n_beta; i++) {
-                const double *r = h_samples + step * row + (size_t)i * (n_par + 2);
-                if (chains[i]->files != NULL)
-                    for (p = 0; p < n_par; p++)
-                        if (chains[i]->files[p] != NULL)
-                            fprintf(chains[i]->files[p], DUMP_FORMAT "\n", r[p]);
-                fprintf(prob_files[i], "%6e\t%6e\n", r[n_par], r[n_par + 1]);
-            }
-        }
-        iter += rounds * n_swap;
-        apemost_swap_round += rounds;
+#define PLAN_BATCH(at, out)                                                                       \
+    do {                                                                                          \
+        (out) = 0;                                                                                \
+        if (run && (max_iterations == 0 || (at) < max_iterations)) {                              \
+            (out) = interval_rounds - ((at) / n_swap) % interval_rounds;                          \
+            if ((out) > max_rounds)                                                               \
+                (out) = max_rounds;                                                               \
+            if (max_iterations != 0 && (out) > (max_iterations - (at) + n_swap - 1) / n_swap)     \
+                (out) = (max_iterations - (at) + n_swap - 1) / n_swap;                            \
+        }                                                                                         \
+    } while (0)
+
+    PLAN_BATCH(iter, rounds_now);
+    if (rounds_now > 0)
+        apemost_hip_or_die(apemost_hip_run(s, rounds_now, n_swap, d_samples[k]), "run_sampler");
+    while (rounds_now > 0) {
+        const unsigned long n_steps = rounds_now * n_swap, iter_after = iter + n_steps;
+        const uint64_t *accepts = h_counts[k], *rejects = h_counts[k] + n_beta;
+        apemost_hip_or_die(apemost_hip_samples_read_async(s, d_samples[k], n_steps, h_samples[k], h_counts[k]),
+                           "samples_read_async");
+        PLAN_BATCH(iter_after, rounds_next);
+        if (rounds_next > 0) /* the device goes on while this batch drains and is written */
+            apemost_hip_or_die(apemost_hip_run(s, rounds_next, n_swap, d_samples[k ^ 1]), "run_sampler");
+        apemost_hip_or_die(apemost_hip_samples_wait(s), "samples_wait");
+        sink_write(&sink, chains, h_samples[k], iter, n_steps);
+        iter = iter_after;
+        apemost_swap_round += rounds_now;
         if (iter % PRINT_PROB_INTERVAL == 0) {
-            apemost_ladder_download(l);
+            const double *last = h_samples[k] + (n_steps - 1) * row; /* chain 0's latest row */
             if (dumpflag) {
+                /* a report on request: the ladder as the device holds it now (a batch ahead of
+                 * the rows just written when another one is already running) */
+                apemost_ladder_download(l);
                 report((const mcmc **)chains, (int)n_beta);
                 dumpflag = 0;
-                for (i = 0; i < n_beta; i++)
-                    fflush(prob_files[i]);
+                sink_flush(&sink);
             }
             fprintf(acceptance_file, "%lu", iter);
             for (i = 0; i < n_beta; i++)
-                fprintf(acceptance_file, "\t%lu", get_params_accepts_global(chains[i]));
+                fprintf(acceptance_file, "\t%lu", (unsigned long)accepts[i]);
             fprintf(acceptance_file, "\n");
             fflush(acceptance_file);
             printf("iteration: %lu, a/r: %.3f(%lu/%lu), v:", iter,
-                   (double)get_params_accepts_global(chains[0]) /
-                       (double)(get_params_accepts_global(chains[0]) + get_params_rejects_global(chains[0])),
-                   get_params_accepts_global(chains[0]), get_params_rejects_global(chains[0]));
-            dump_vector(get_params(chains[0]));
+                   (double)accepts[0] / (double)(accepts[0] + rejects[0]), (unsigned long)accepts[0],
+                   (unsigned long)rejects[0]);
+            printf("Vector%ud[", n_par); /* dump_vector's format, from the row instead of a gsl_vector */
+            for (i = 0; i < n_par; i++)
+                printf("%f%s", last[i], i + 1 < n_par ? ";" : "]");
             printf(" [%d/%lu ticks]\r", get_duration(), get_ticks_per_second());
             fflush(stdout);
         }
+        rounds_now = rounds_next;
+        k ^= 1;
     }
+#undef PLAN_BATCH
     apemost_ladder_download(l);
-    apemost_hip_samples_free(s, d_samples);
+    for (i = 0; i < 2; i++) {
+        apemost_hip_samples_free(s, d_samples[i]);
+        apemost_hip_host_free(h_samples[i]);
+        apemost_hip_host_free(h_counts[i]);
+    }
     apemost_ladder_close(l);
-    free(h_samples);
     fclose(acceptance_file);
-    for (i = 0; i < n_beta; i++)
-        fclose(prob_files[i]);
-    mem_free(prob_files);
+    sink_close(&sink);
     printf("handled %lu iterations on %d chains\n", iter, n_beta);
 }
 

@@ -4,6 +4,7 @@
 #include <string.h>
 #include "mcmc.h"
 #include "parallel_tempering_config.h"
+#include "apemost_bridge.h"
 #include "debug.h"
 #include "define_defaults.h"
 #include "gsl_helper.h"
@@ -84,7 +85,7 @@ mcmc **setup_chains() {
             mcmc_reuse_data(chains[i], chains[0]);
         mcmc_check(chains[i]);
         t = (parallel_tempering_mcmc *)mem_calloc(1, sizeof(parallel_tempering_mcmc));
-        t->chain_id = i;
+        apemost_chain_place(chains[i], i);
         chains[i]->additional_data = t;
         set_beta(chains[i], 1.0);
     }

@@ -214,6 +214,21 @@ int apemost_hip_samples_alloc(apemost_hip_sampler *s, uint64_t n_steps, double *
 int apemost_hip_samples_read(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps, double *host);
 int apemost_hip_samples_free(apemost_hip_sampler *s, double *d_samples);
 
+/* The same read without stalling the sampler: the copy is queued behind everything launched so far
+ * but runs on a second stream, so launches issued after this call overlap with it (double-buffered
+ * sample sinks: the device fills buffer B while buffer A drains to the host).  host_samples should
+ * be pinned memory (apemost_hip_host_alloc).  counters, if not NULL, receives [2][n_chains]
+ * uint64: m->accept then m->reject of every chain as they stand after the launches issued so far
+ * (what the reference prints to acceptance_rate.dump, src/parallel_tempering.c:320-326), without a
+ * host synchronisation of the sampler's stream.  apemost_hip_samples_wait blocks until the latest
+ * such read has landed (and reports a void launch like apemost_hip_samples_read). */
+int apemost_hip_samples_read_async(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
+                                   double *host_samples, uint64_t *counters);
+int apemost_hip_samples_wait(apemost_hip_sampler *s);
+/* page-locked host memory for those reads */
+int apemost_hip_host_alloc(size_t bytes, void **p);
+int apemost_hip_host_free(void *p);
+
 /* pair index `a` that tempering_interaction() will pick at swap-stream position
  * `round` (parallel_tempering_decide_swap_now, interaction.c:87-97); -1 if n_global==1 */
 int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t n_chains_global);
@@ -227,6 +242,26 @@ int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t n_chains_gl
 int32_t apemost_hip_edge_doubles(int32_t n_par);
 int apemost_hip_edge_export(apemost_hip_sampler *s, int side, double *d_buf);
 int apemost_hip_edge_import(apemost_hip_sampler *s, int side, const double *d_buf);
+
+/* ---- one process, several devices (or several shards on one device) --------------------------
+ * The same block-partitioned ladder as the one-process-per-GPU driver, for hosts that
+ * stay a single process (the C host layer with APEMOST_DEVICES=0,1,...): shards[j] holds chains
+ * [offset_j, offset_j + n_j) of the same ladder (same seed, same n_chains_global, offsets
+ * ascending and contiguous), each on its own device and stream.
+ *
+ * apemost_hip_edge_exchange: the pending swap attempt picked the pair that straddles lower|upper:
+ * both shards export their edge record, the records cross with hipMemcpyPeerAsync (xGMI between
+ * devices, a device copy within one), and land in the halo rows the next launch reads -- all
+ * stream-ordered with events, no host synchronisation.
+ *
+ * apemost_hip_run_shards: run_sampler() over all shards in lock step: rounds are batched into
+ * multi-round launches up to the next swap attempt that needs a neighbour's record, exactly as
+ * apemost_hip_run does on one device; d_samples[j] (may be NULL) receives shard j's rows,
+ * [n_rounds*n_swap][n_j][n_par+2].  The result is bit-identical to the whole ladder on one
+ * sampler. */
+int apemost_hip_edge_exchange(apemost_hip_sampler *lower, apemost_hip_sampler *upper);
+int apemost_hip_run_shards(apemost_hip_sampler **shards, int32_t n_shards, uint64_t n_rounds, uint32_t n_swap,
+                           double **d_samples);
 
 /* ---- calibration ---------------------------------------------------------- */
 void apemost_hip_calib_defaults(apemost_hip_calib_config *c);

@@ -138,7 +138,7 @@ def test_calibrate_first_and_rest_match_oracle(name, skip):
     rng = orc.Rng(orc.RNG_STREAMS, 9, lad)
     s = HipSampler(w.model, w.n_par, n_beta, w.data, seed=9)
     s.set_state(st)
-    dcfg, ocfg = _cfgs()
+    dcfg, ocfg = _cfgs(limit=100000)       # the cold chain needs ~22 000 sweeps from the params-file widths
     assert s.calibrate_first(dcfg) == orc.calibrate_first(lad, rng, ocfg) == 0
     assert_match(s.get_state(), lad, rng, what="calibrate_first " + name)
     status, beta_0, factors = s.calibrate_rest(dcfg, skip_calibrate_allchains=skip)

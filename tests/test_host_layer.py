@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from apemost_amd import build, capi, workloads as wl
+from tests import hostlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "apemost_amd", "host")
@@ -20,14 +21,9 @@ REF = "/root/reference"
 STRICT = "-std=c99 -fopenmp -Wall -Werror -Wextra -ansi -pedantic"   # the reference Makefile's CFLAGS
 
 
-def _make(out, app=None, main=None, ccflags="", strict=STRICT):
-    cmd = ["make", "-s", "-C", HOST, "OUT=" + out, "STRICT=" + strict, "CCFLAGS=" + ccflags]
-    if app:
-        cmd.append("APP=" + app)
-    if main:
-        cmd.append("MAIN=" + main)
-    subprocess.check_call(cmd)
-    return out
+def _make(out, app=None, main=None, ccflags="", strict=STRICT, shared=False):
+    build.build_hip()
+    return hostlib.make(out, app, main, ccflags, strict, shared)
 
 
 def test_abi_library_exports_every_declared_symbol():
@@ -63,6 +59,116 @@ def test_reference_apps_link_unchanged_and_eval_matches_manual(tmp_path):
     assert abs(prob - (-1.480898044165363e+01)) < 5e-14 and prior == 0.0
     chk = subprocess.check_output([str(tmp_path / "generic_main_simplesin.exe"), "check"], cwd=str(work)).decode()
     assert "N_BETA: 8" in chk and "params\tfound" in chk
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_reference_unit_tests_link_unchanged_and_pass(tmp_path, golden_dir):
+    """the reference's own TAP suite (tests/tests.c + run-tests.c: histogram, chain construction,
+    parser on its fixtures, append, RNG wrappers, mod_double, dump files) compiled unchanged against
+    the host layer under the reference's flags: 8 of 8 ok.  Only the binary runs; on the GPU box the
+    reference tree does not exist and this test is skipped."""
+    exe = _make(str(tmp_path / "tests.exe"), app=REF + "/tests/tests.c", main=REF + "/tests/run-tests.c",
+                ccflags="-DN_BETA=4")
+    work = tmp_path / "w"
+    (work / "tests").mkdir(parents=True)
+    for f in ("testinput1", "testlc.dat"):           # the fixtures the suite reads (tests/tests.c:90,135)
+        (work / "tests" / f).write_bytes(open(os.path.join(golden_dir, f), "rb").read())
+    out = subprocess.check_output([exe], cwd=str(work)).decode()
+    tap = [l for l in out.splitlines() if re.match(r"(not )?ok \d+", l)]
+    assert tap == ["ok %d" % i for i in range(1, 9)], out[-2000:]
+    assert "all 8 tests successful" in out
+
+
+def test_tempering_struct_keeps_the_reference_layout(tmp_path):
+    """applications allocate parallel_tempering_mcmc themselves (apps/eval_main.c:50): two fields,
+    16 bytes, as src/parallel_tempering_beta.h:65-76 declares it"""
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mcmc.h"\n#include "parallel_tempering_beta.h"\n'
+                   'int main(void) { printf("%lu %lu %lu\\n", (unsigned long)sizeof(parallel_tempering_mcmc),\n'
+                   '(unsigned long)offsetof(parallel_tempering_mcmc, beta), (unsigned long)offsetof(parallel_tempering_mcmc, swapcount)); return 0; }\n')
+    exe = str(tmp_path / "probe.exe")
+    subprocess.check_call(["gcc", "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(HOST, "gsl"),
+                           "-I" + os.path.join(ROOT, "include"), "-DWITHOUT_GARBAGE_COLLECTOR", str(src), "-o", exe])
+    assert subprocess.check_output([exe]).split() == [b"16", b"0", b"8"]
+
+
+def _write_inputs(work, w):
+    work.mkdir(exist_ok=True)
+    (work / "params").write_text(w.params_file_text())
+    (work / "data").write_text(w.data_file_text())
+
+
+def test_library_flavour_set_function_and_quirk_q6(tmp_path):
+    """libapemost.so (reference Makefile:48-49, apps/library.c): a client registers LogLike and Prior;
+    calc_model() then sets prior and prob = beta * (prior + loglike) -- the prior is tempered too
+    (SURVEY quirk Q6).  Host path only, no GPU."""
+    import ctypes as C
+    lib = _make(str(tmp_path / "libapemost.so"), ccflags="-DN_BETA=4", shared=True)
+    L = hostlib.load(lib)
+    w = wl.simplesin(n_data=32, n_chain=4)
+    _write_inputs(tmp_path / "w", w)
+    m = L.mcmc_load(str(tmp_path / "w" / "params").encode(), str(tmp_path / "w" / "data").encode())
+    keep = hostlib.attach_tempering(L, m, 0.25)
+    calls = []
+
+    def loglike(mp, old):
+        calls.append("L")
+        return -3.5 * mp.contents.params.contents.data[0] - mp.contents.data.contents.size1
+
+    def prior(mp, old):
+        calls.append("P")
+        return -2.0
+
+    cb_l, cb_p = hostlib.CALLBACK(loglike), hostlib.CALLBACK(prior)
+    L.set_function.argtypes = [hostlib.CALLBACK, hostlib.CALLBACK]
+    L.set_function(cb_l, cb_p)
+    L.calc_model(m, None)
+    assert calls == ["P", "L"]
+    assert m.contents.prior == -2.0
+    assert m.contents.prob == 0.25 * (-2.0 + (-3.5 * w.start[0] - 32))
+    L.mcmc_free(m)
+    del keep
+
+
+BETA_LADDERS = ["chebyshev_beta", "equidistant_beta", "equidistant_temperature", "chebyshev_temperature",
+                "equidistant_stepwidth", "chebyshev_stepwidth", "hot_chains"]
+
+
+@pytest.mark.parametrize("kind,name", list(enumerate(BETA_LADDERS)))
+def test_beta_ladder_and_beta_0_match_oracle(kind, name, tmp_path):
+    """get_chain_beta for every BETA_ALIGNMENT (src/parallel_tempering_beta.c:53-90) and calc_beta_0
+    (:92-102): the C host layer and the Python mirror against the oracle's restatement"""
+    import ctypes as C
+    from apemost_amd import sampler
+    from apemost_amd.state import LadderState
+    from oracle import oracle as orc
+    order = {"chebyshev_beta": 0, "equidistant_beta": 1, "equidistant_temperature": 2, "chebyshev_temperature": 3,
+             "equidistant_stepwidth": 4, "chebyshev_stepwidth": 5, "hot_chains": 6}
+    lib = _make(str(tmp_path / "lib.so"), ccflags="-DN_BETA=4 -DBETA_ALIGNMENT=" + name, shared=True)
+    L = hostlib.load(lib)
+    for n_beta in (1, 2, 8, 20, 128):
+        for beta_0 in (0.02, 0.4):
+            for i in range(n_beta):
+                ref = orc.get_chain_beta(order[name], i, n_beta, beta_0)
+                assert L.get_chain_beta(i, n_beta, beta_0) == ref, (name, n_beta, i)
+                assert abs(sampler.get_chain_beta(kind, i, n_beta, beta_0) - ref) <= 4e-16 * abs(ref)
+            cold = L.get_chain_beta(0, n_beta, beta_0)      # chain 0 is the cold chain
+            assert abs(cold - (beta_0 if name == "hot_chains" and n_beta > 1 else 1.0)) < 4e-16
+    if kind == 0:
+        w = wl.pulse(n_data=16, n_chain=3)
+        _write_inputs(tmp_path / "w", w)
+        m = L.mcmc_load(str(tmp_path / "w" / "params").encode(), str(tmp_path / "w" / "data").encode())
+        factors = np.array([1.3, 0.7, 1.0, 2.2, 0.9, 1.1])
+        fv = L.gsl_vector_alloc(6)
+        hostlib.set_vec(fv, factors)
+        lad = orc.Ladder.from_params(w.model, 3, w.start, w.pmin, w.pmax, w.step, w.data)
+        ref = orc.lib().orc_calc_beta_0(C.byref(lad.c_state()), 0, factors.ctypes.data_as(C.POINTER(C.c_double)))
+        got = L.calc_beta_0(m, fv)
+        assert abs(got - ref) <= 1e-15 * ref and 0 < got < 1
+        st = LadderState.from_params(3, w.start, w.pmin, w.pmax, w.step)
+        assert abs(sampler.calc_beta_0(st, 0, factors) - ref) <= 1e-15 * ref
+        L.gsl_vector_free(fv)
+        L.mcmc_free(m)
 
 
 def _rt(a):
