@@ -43,6 +43,21 @@ def build_stamps(verbose=False, wave=0):
     return out
 
 
+def build_dev(models, waves, out=None, extra=(), verbose=False):
+    """development build: only the given models (ids) and workgroup shapes (wave counts) are
+    instantiated, which compiles in seconds instead of minutes.  Never the product library:
+    select it with APEMOST_HIP_LIB=<out>."""
+    out = out or os.path.join(HERE, "libapemost_hip_dev.so")
+    mm = sum(1 << m for m in models)
+    wm = sum(1 << w for w in waves)
+    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_DEV_MODELS=%d" % mm, "-DAPEMOST_DEV_WAVES=%d" % wm] + list(extra) + [
+        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out, os.path.join(CSRC, "apemost_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
     return [build_hip(force, verbose)]
 

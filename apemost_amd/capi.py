@@ -60,7 +60,8 @@ EXPORTS = [
     "apemost_hip_samples_wait", "apemost_hip_host_alloc", "apemost_hip_host_free", "apemost_hip_swap_pair",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_edge_exchange", "apemost_hip_run_shards",
-    "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_rng_raw",
+    "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_calibrate_begin",
+    "apemost_hip_calibrate_end", "apemost_hip_rng_raw",
     "apemost_hip_rng_attempts", "apemost_hip_timer_begin", "apemost_hip_timer_end",
 ]
 
@@ -128,6 +129,8 @@ def lib():
     L.apemost_hip_calib_defaults.restype = None
     L.apemost_hip_calibrate_chains.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(CalibConfig), C.c_int,
                                                C.POINTER(C.c_int32), _up]
+    L.apemost_hip_calibrate_begin.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(CalibConfig), C.c_int]
+    L.apemost_hip_calibrate_end.argtypes = [vp, C.POINTER(C.c_int32), _up]
     L.apemost_hip_rng_raw.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
                                       C.POINTER(C.c_uint32)]
     L.apemost_hip_rng_attempts.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,

@@ -669,6 +669,7 @@ struct apemost_hip_sampler {
     int *d_status;
     u64 *d_iters;
     int calib_capacity;
+    int calib_pending; // chains of a calibrate_begin whose results calibrate_end has not collected yet
     double *edge_out, *edge_in;  // edge records for in-process shard exchanges (created on first use)
     hipEvent_t ev_exported, ev_imported;
     hipStream_t copy_stream; // drains sample rows while the next launch runs (created on first use)
@@ -911,6 +912,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->d_status = nullptr;
     s->d_iters = nullptr;
     s->calib_capacity = 0;
+    s->calib_pending = 0;
     s->stream = nullptr;
     s->ev0 = s->ev1 = nullptr;
     s->copy_stream = nullptr;
@@ -1155,53 +1157,91 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
     return hipGetLastError();
 }
 
-template <int MODEL, bool LDS>
-static hipError_t launch_w(int waves, KernelKind kind, bool producers, bool coop, int grid, size_t lds, hipStream_t st,
-                           const void *args) {
-    switch (waves) {
-    case 1:
-        return launch_one<MODEL, 1, LDS>(kind, producers, coop, grid, lds, st, args);
-    case 2:
-        return launch_one<MODEL, 2, LDS>(kind, producers, coop, grid, lds, st, args);
-    case 4:
-        return launch_one<MODEL, 4, LDS>(kind, producers, coop, grid, lds, st, args);
-    case 8:
-        return launch_one<MODEL, 8, LDS>(kind, producers, coop, grid, lds, st, args);
-    default:
-        return launch_one<MODEL, 6, LDS>(kind, producers, coop, grid, lds, st, args);
-    }
+// ---- run-time (model, waves) -> compile-time instantiation ----
+// A development build can restrict what is instantiated (a full build compiles 4 models x 5
+// workgroup shapes x every kernel and takes minutes): -DAPEMOST_DEV_MODELS=<bit per model>
+// -DAPEMOST_DEV_WAVES=<bit per wave count>.  The product build has every bit set.
+#ifndef APEMOST_DEV_MODELS
+#define APEMOST_DEV_MODELS 0xF
+#endif
+#ifndef APEMOST_DEV_WAVES
+#define APEMOST_DEV_WAVES 0x156 // 1, 2, 4, 6, 8
+#endif
+constexpr bool built(int model, int waves) {
+    return ((APEMOST_DEV_MODELS >> model) & 1) && ((APEMOST_DEV_WAVES >> waves) & 1);
 }
 
-template <int MODEL>
-static hipError_t launch_m(bool lds_data, int waves, KernelKind kind, bool producers, bool coop, int grid, size_t lds,
-                           hipStream_t st, const void *args) {
-    return lds_data ? launch_w<MODEL, true>(waves, kind, producers, coop, grid, lds, st, args)
-                    : launch_w<MODEL, false>(waves, kind, producers, coop, grid, lds, st, args);
+// f.template run<MODEL, WAVES>() for the sampler's model and workgroup shape
+template <int MODEL, class F>
+static hipError_t dispatch_w(int waves, const F &f) {
+    switch (waves) {
+    case 1:
+        if constexpr (built(MODEL, 1))
+            return f.template run<MODEL, 1>();
+        break;
+    case 2:
+        if constexpr (built(MODEL, 2))
+            return f.template run<MODEL, 2>();
+        break;
+    case 4:
+        if constexpr (built(MODEL, 4))
+            return f.template run<MODEL, 4>();
+        break;
+    case 6:
+        if constexpr (built(MODEL, 6))
+            return f.template run<MODEL, 6>();
+        break;
+    case 8:
+        if constexpr (built(MODEL, 8))
+            return f.template run<MODEL, 8>();
+        break;
+    }
+    return hipErrorInvalidDeviceFunction; // not part of this (development) build
 }
+
+template <class F>
+static hipError_t dispatch(int model, int waves, const F &f) {
+    switch (model) {
+    case APEMOST_MODEL_SIMPLESIN:
+        return dispatch_w<APEMOST_MODEL_SIMPLESIN>(waves, f);
+    case APEMOST_MODEL_PULSE:
+        return dispatch_w<APEMOST_MODEL_PULSE>(waves, f);
+    case APEMOST_MODEL_PULSE_VROT:
+        return dispatch_w<APEMOST_MODEL_PULSE_VROT>(waves, f);
+    case APEMOST_MODEL_SINE3:
+        return dispatch_w<APEMOST_MODEL_SINE3>(waves, f);
+    }
+    return hipErrorInvalidDeviceFunction;
+}
+
+struct LaunchOp {
+    KernelKind kind;
+    bool lds_data, producers, coop;
+    int grid;
+    size_t lds;
+    hipStream_t st;
+    const void *args;
+    template <int MODEL, int WAVES>
+    hipError_t run() const {
+        return lds_data ? launch_one<MODEL, WAVES, true>(kind, producers, coop, grid, lds, st, args)
+                        : launch_one<MODEL, WAVES, false>(kind, producers, coop, grid, lds, st, args);
+    }
+};
 
 // stage_data: a launch that walks the data vector only a few times (n_swap < 4, single
 // likelihood evaluations) reads it through L2 instead of copying it into LDS first
 static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true,
                   bool coop = false) {
-    hipError_t err;
-    const bool lds_data = s->lds_data && stage_data;
-    const size_t lds_bytes = lds_data ? s->lds_bytes : s->lds_fixed_bytes;
-    const int w = s->waves;
-    const bool pr = s->producers;
-    switch (s->cfg.model) {
-    case APEMOST_MODEL_SIMPLESIN:
-        err = launch_m<APEMOST_MODEL_SIMPLESIN>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
-        break;
-    case APEMOST_MODEL_PULSE:
-        err = launch_m<APEMOST_MODEL_PULSE>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
-        break;
-    case APEMOST_MODEL_PULSE_VROT:
-        err = launch_m<APEMOST_MODEL_PULSE_VROT>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
-        break;
-    default:
-        err = launch_m<APEMOST_MODEL_SINE3>(lds_data, w, kind, pr, coop, grid, lds_bytes, s->stream, args);
-        break;
-    }
+    LaunchOp op;
+    op.kind = kind;
+    op.lds_data = s->lds_data && stage_data;
+    op.producers = s->producers;
+    op.coop = coop;
+    op.grid = grid;
+    op.lds = op.lds_data ? s->lds_bytes : s->lds_fixed_bytes;
+    op.st = s->stream;
+    op.args = args;
+    const hipError_t err = dispatch(s->cfg.model, s->waves, op);
     if (err != hipSuccess)
         return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));
     return APEMOST_HIP_OK;
@@ -1298,75 +1338,46 @@ static hipError_t set_lds_attr(size_t bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int MODEL>
-static hipError_t set_lds_attr_w(int waves, size_t bytes) {
-    switch (waves) {
-    case 1:
-        return set_lds_attr<MODEL, 1>(bytes);
-    case 2:
-        return set_lds_attr<MODEL, 2>(bytes);
-    case 4:
-        return set_lds_attr<MODEL, 4>(bytes);
-    case 8:
-        return set_lds_attr<MODEL, 8>(bytes);
-    default:
-        return set_lds_attr<MODEL, 6>(bytes);
+struct LdsAttrOp {
+    size_t bytes;
+    template <int MODEL, int WAVES>
+    hipError_t run() const {
+        return set_lds_attr<MODEL, WAVES>(bytes);
     }
-}
+};
 
 // blocks of the round kernel one CU admits (occupancy API: registers, LDS, wave slots)
-template <int MODEL, bool LDS>
-static hipError_t round_occupancy_w(int waves, bool producers, size_t lds_bytes, int *blocks) {
-    switch (waves) {
-    case 1:
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 1, LDS, false>, block_threads(1, false), lds_bytes);
-    case 2:
-        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 2, LDS, true>, block_threads(2, true), lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 2, LDS, false>, block_threads(2, false), lds_bytes);
-    case 4:
-        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 4, LDS, true>, block_threads(4, true), lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 4, LDS, false>, block_threads(4, false), lds_bytes);
-    case 8:
-        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 8, LDS, true>, block_threads(8, true), lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 8, LDS, false>, block_threads(8, false), lds_bytes);
-    default:
-        return producers ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 6, LDS, true>, block_threads(6, true), lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, 6, LDS, false>, block_threads(6, false), lds_bytes);
+template <bool LDS>
+struct OccupancyOp {
+    bool producers;
+    size_t lds_bytes;
+    int *blocks;
+    template <int MODEL, int WAVES>
+    hipError_t run() const {
+        constexpr bool kCanProduce = has_producer(WAVES);
+        if (kCanProduce && producers)
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
+                                                                block_threads(WAVES, true), lds_bytes);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, false>,
+                                                            block_threads(WAVES, false), lds_bytes);
     }
-}
+};
 
 template <bool LDS>
 static hipError_t round_occupancy(int model, int waves, bool producers, size_t lds_bytes, int *blocks) {
-    switch (model) {
-    case APEMOST_MODEL_SIMPLESIN:
-        return round_occupancy_w<APEMOST_MODEL_SIMPLESIN, LDS>(waves, producers, lds_bytes, blocks);
-    case APEMOST_MODEL_PULSE:
-        return round_occupancy_w<APEMOST_MODEL_PULSE, LDS>(waves, producers, lds_bytes, blocks);
-    case APEMOST_MODEL_PULSE_VROT:
-        return round_occupancy_w<APEMOST_MODEL_PULSE_VROT, LDS>(waves, producers, lds_bytes, blocks);
-    default:
-        return round_occupancy_w<APEMOST_MODEL_SINE3, LDS>(waves, producers, lds_bytes, blocks);
-    }
+    OccupancyOp<LDS> op;
+    op.producers = producers;
+    op.lds_bytes = lds_bytes;
+    op.blocks = blocks;
+    return dispatch(model, waves, op);
 }
 
 static int enable_big_lds(apemost_hip_sampler *s) {
     if (!s->lds_data || s->lds_bytes <= 64 * 1024)
         return APEMOST_HIP_OK;
-    hipError_t e;
-    switch (s->cfg.model) {
-    case APEMOST_MODEL_SIMPLESIN:
-        e = set_lds_attr_w<APEMOST_MODEL_SIMPLESIN>(s->waves, s->lds_bytes);
-        break;
-    case APEMOST_MODEL_PULSE:
-        e = set_lds_attr_w<APEMOST_MODEL_PULSE>(s->waves, s->lds_bytes);
-        break;
-    case APEMOST_MODEL_PULSE_VROT:
-        e = set_lds_attr_w<APEMOST_MODEL_PULSE_VROT>(s->waves, s->lds_bytes);
-        break;
-    default:
-        e = set_lds_attr_w<APEMOST_MODEL_SINE3>(s->waves, s->lds_bytes);
-        break;
-    }
+    LdsAttrOp op;
+    op.bytes = s->lds_bytes;
+    const hipError_t e = dispatch(s->cfg.model, s->waves, op);
     if (e != hipSuccess)
         return fail(APEMOST_HIP_ERR_RUNTIME, "hipFuncSetAttribute(LDS %zu B): %s", s->lds_bytes,
                     hipGetErrorString(e));
@@ -1722,25 +1733,29 @@ extern "C" void apemost_hip_calib_defaults(apemost_hip_calib_config *c) {
     c->adjust_step = 0.5;
 }
 
-extern "C" int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t count,
-                                            const apemost_hip_calib_config *c, int burn_in_only,
-                                            int32_t *status, uint64_t *iters) {
+// markov_chain_calibrate for chains [first, first+count): the launch ...
+extern "C" int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first, int32_t count,
+                                           const apemost_hip_calib_config *c, int burn_in_only) {
     CHECK_S(s);
     if (!c || first < 0 || count < 1 || first + count > s->cfg.n_chains)
         return fail(APEMOST_HIP_ERR_INVALID, "calibrate_chains: chains [%d,%d) outside [0,%d)", first,
                     first + count, s->cfg.n_chains);
     if (c->iter_readjust == 0)
         return fail(APEMOST_HIP_ERR_INVALID, "iter_readjust must be > 0");
+    if (s->calib_pending)
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_begin: the previous calibration was not collected (calibrate_end)");
     if (count > s->calib_capacity) {
         if (s->d_status)
             hipFree(s->d_status);
         if (s->d_iters)
             hipFree(s->d_iters);
+        s->d_status = nullptr;
+        s->d_iters = nullptr;
+        s->calib_capacity = 0;
         HIP_TRY(hipMalloc((void **)&s->d_status, count * sizeof(int)));
         HIP_TRY(hipMalloc((void **)&s->d_iters, count * sizeof(u64)));
         s->calib_capacity = count;
     }
-    int rc;
     CalibArgs a;
     a.d = s->d;
     a.sh = s->sh;
@@ -1750,14 +1765,28 @@ extern "C" int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t firs
     a.cfg = *c;
     a.status = s->d_status;
     a.iters = s->d_iters;
-    rc = launch(s, K_CALIB, count, &a);
+    const int rc = launch(s, K_CALIB, count, &a);
     if (rc)
         return rc;
+    s->calib_pending = count;
+    return APEMOST_HIP_OK;
+}
+
+// ... and its results: status[count] / iters[count] of the chains of the matching begin
+extern "C" int apemost_hip_calibrate_end(apemost_hip_sampler *s, int32_t *status, uint64_t *iters) {
+    CHECK_S(s);
+    const int count = s->calib_pending;
+    if (count <= 0)
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_end without calibrate_begin");
+    s->calib_pending = 0;
     std::vector<int> st(count);
     std::vector<u64> it(count);
     HIP_TRY(hipMemcpyAsync(st.data(), s->d_status, count * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(it.data(), s->d_iters, count * sizeof(u64), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    int rc = check_handoff(s);
+    if (rc)
+        return rc;
     int worst = 0;
     for (int i = 0; i < count; i++) {
         if (status)
@@ -1771,6 +1800,13 @@ extern "C" int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t firs
         return fail(APEMOST_HIP_ERR_CALIBRATION, "calibration failed: %s",
                     worst == 1 ? "a step width became too large" : "iteration limit reached");
     return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t count,
+                                            const apemost_hip_calib_config *c, int burn_in_only,
+                                            int32_t *status, uint64_t *iters) {
+    const int rc = apemost_hip_calibrate_begin(s, first, count, c, burn_in_only);
+    return rc ? rc : apemost_hip_calibrate_end(s, status, iters);
 }
 
 static int rng_device(int device) {

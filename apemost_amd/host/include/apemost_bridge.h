@@ -17,7 +17,16 @@ apemost_ladder *apemost_ladder_open(mcmc **chains, unsigned int n_chains);
 void apemost_ladder_upload(apemost_ladder *l);
 void apemost_ladder_download(apemost_ladder *l);
 void apemost_ladder_close(apemost_ladder *l);
-apemost_hip_sampler *apemost_ladder_sampler(apemost_ladder *l);
+apemost_hip_sampler *apemost_ladder_sampler(apemost_ladder *l); /* shard 0 */
+/* shards of the ladder (APEMOST_DEVICES=0,1,...: one per listed device; default one) */
+#define APEMOST_MAX_SHARDS 16
+unsigned int apemost_ladder_shards(const apemost_ladder *l);
+apemost_hip_sampler *apemost_ladder_shard(apemost_ladder *l, unsigned int k);
+unsigned int apemost_ladder_shard_first(const apemost_ladder *l, unsigned int k); /* k = shards: n_chains */
+void apemost_ladder_calc_model(apemost_ladder *l, unsigned int first, unsigned int count);
+int apemost_ladder_calibrate(apemost_ladder *l, unsigned int first, unsigned int count,
+                             const apemost_hip_calib_config *c, int burn_in_only, int32_t *status);
+void apemost_ladder_run(apemost_ladder *l, unsigned long n_rounds, unsigned int n_swap, double **d_samples);
 /* cached one-chain twin used by the single-chain API (markov_chain_step & co) */
 apemost_ladder *apemost_single(mcmc *m);
 /* The engine's per-chain RNG address: which stream family the chain draws from (its position in

@@ -15,11 +15,17 @@
 
 unsigned long apemost_swap_round = 0;
 
+/* A ladder on the device(s): one sampler per shard.  With APEMOST_DEVICES=0,1,... the ladder is
+ * block-partitioned over those devices (chain i on shard floor(i*G/n)); a device named
+ * twice carries two shards (how the tests run it on one GPU).  Without it: one shard on
+ * APEMOST_DEVICE (default 0). */
 struct apemost_ladder {
     mcmc **chains;
     unsigned int n, n_par;
-    apemost_hip_sampler *s;
-    apemost_hip_state_view v; /* host staging arrays, structure of arrays */
+    unsigned int n_shards;
+    apemost_hip_sampler *s[APEMOST_MAX_SHARDS];
+    unsigned int lo[APEMOST_MAX_SHARDS + 1]; /* shard k holds chains [lo[k], lo[k+1]) */
+    apemost_hip_state_view v; /* host staging arrays for the whole ladder, structure of arrays */
 };
 
 void apemost_hip_or_die(int rc, const char *what) {
@@ -128,14 +134,20 @@ static uint64_t circular_mask(void) {
     return mask;
 }
 
+static int default_device(void) {
+    const char *dev = getenv("APEMOST_DEVICE");
+    return dev ? atoi(dev) : 0;
+}
+
 static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned int n_chains, long chain_offset,
-                                           long n_global) {
+                                           long n_global, int device) {
     apemost_hip_config cfg;
     apemost_hip_sampler *s = NULL;
-    const char *dev = getenv("APEMOST_DEVICE"), *waves = getenv("APEMOST_WAVES");
+    const char *waves = getenv("APEMOST_WAVES"), *flags = getenv("APEMOST_FLAGS");
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = APEMOST_HIP_ABI_VERSION;
-    cfg.device = dev ? atoi(dev) : 0;
+    cfg.device = device;
+    cfg.flags = flags ? atoi(flags) : 0;
     cfg.model = model;
     cfg.n_par = (int)m->n_par;
     cfg.n_chains = (int)n_chains;
@@ -234,7 +246,7 @@ int apemost_detect_model(mcmc *m) {
             continue;
         if (forced && strcmp(forced, model_name(model)) != 0)
             continue;
-        s = create_sampler(m, model, 1, 0, 1);
+        s = create_sampler(m, model, 1, 0, 1, default_device());
         apemost_hip_or_die(apemost_hip_loglike(s, DETECT_POINTS, pts, beta, dev_prob, dev_prior),
                            "apemost_hip_loglike");
         apemost_hip_destroy(s);
@@ -305,6 +317,29 @@ static void free_view(apemost_hip_state_view *v) {
     free(v->ticks);
 }
 
+/* the staging arrays of shard k: the same arrays, offset to its first chain */
+static apemost_hip_state_view shard_view(const apemost_ladder *l, unsigned int k) {
+    const size_t c = l->lo[k], np = l->n_par;
+    apemost_hip_state_view v = l->v;
+    v.params += c * np;
+    v.params_best += c * np;
+    v.step += c * np;
+    v.pmin += c * np;
+    v.pmax += c * np;
+    v.params_accepts += c * np;
+    v.params_rejects += c * np;
+    v.beta += c;
+    v.prob += c;
+    v.prior += c;
+    v.prob_best += c;
+    v.accept += c;
+    v.reject += c;
+    v.n_iter += c;
+    v.swapcount += c;
+    v.ticks += c;
+    return v;
+}
+
 void apemost_ladder_upload(apemost_ladder *l) {
     const unsigned int np = l->n_par;
     unsigned int c, p;
@@ -330,13 +365,19 @@ void apemost_ladder_upload(apemost_ladder *l) {
         l->v.reject[c] = m->reject;
         l->v.n_iter[c] = m->n_iter;
     }
-    apemost_hip_or_die(apemost_hip_set_state(l->s, &l->v), "apemost_hip_set_state");
+    for (c = 0; c < l->n_shards; c++) {
+        const apemost_hip_state_view part = shard_view(l, c);
+        apemost_hip_or_die(apemost_hip_set_state(l->s[c], &part), "apemost_hip_set_state");
+    }
 }
 
 void apemost_ladder_download(apemost_ladder *l) {
     const unsigned int np = l->n_par;
     unsigned int c, p;
-    apemost_hip_or_die(apemost_hip_get_state(l->s, &l->v), "apemost_hip_get_state");
+    for (c = 0; c < l->n_shards; c++) {
+        const apemost_hip_state_view part = shard_view(l, c);
+        apemost_hip_or_die(apemost_hip_get_state(l->s[c], &part), "apemost_hip_get_state");
+    }
     for (c = 0; c < l->n; c++) {
         mcmc *m = l->chains[c];
         for (p = 0; p < np; p++) {
@@ -359,28 +400,105 @@ void apemost_ladder_download(apemost_ladder *l) {
     }
 }
 
+/* APEMOST_DEVICES=0,1,...: device ordinal of every shard, in ladder order */
+static unsigned int parse_devices(int *devices) {
+    const char *spec = getenv("APEMOST_DEVICES");
+    unsigned int n = 0;
+    while (spec != NULL && *spec != 0 && n < APEMOST_MAX_SHARDS) {
+        devices[n++] = atoi(spec);
+        spec = strchr(spec, ',');
+        if (spec != NULL)
+            spec++;
+    }
+    if (n == 0)
+        devices[n++] = default_device();
+    return n;
+}
+
 apemost_ladder *apemost_ladder_open(mcmc **chains, unsigned int n_chains) {
     apemost_ladder *l = (apemost_ladder *)calloc(1, sizeof(apemost_ladder));
     const int model = apemost_detect_model(chains[0]);
+    int devices[APEMOST_MAX_SHARDS];
+    unsigned int k, shards = parse_devices(devices);
     l->chains = chains;
     l->n = n_chains;
     l->n_par = chains[0]->n_par;
-    l->s = create_sampler(chains[0], model, n_chains, 0, n_chains);
+    /* every shard at least two chains (shard 0 calibrates chains 0 and 1 by itself) */
+    while (shards > 1 && n_chains < 2 * shards)
+        shards--;
+    l->n_shards = shards;
+    for (k = 0; k <= shards; k++)
+        l->lo[k] = (unsigned int)(((unsigned long)k * n_chains + shards - 1) / shards);
+    for (k = 0; k < shards; k++)
+        l->s[k] = create_sampler(chains[0], model, l->lo[k + 1] - l->lo[k], (long)l->lo[k], (long)n_chains,
+                                 devices[k]);
     alloc_view(l);
     apemost_ladder_upload(l);
-    apemost_hip_or_die(apemost_hip_set_round(l->s, apemost_swap_round, 0), "apemost_hip_set_round");
+    for (k = 0; k < shards; k++)
+        apemost_hip_or_die(apemost_hip_set_round(l->s[k], apemost_swap_round, 0), "apemost_hip_set_round");
     return l;
 }
 
 void apemost_ladder_close(apemost_ladder *l) {
+    unsigned int k;
     if (l == NULL)
         return;
-    apemost_hip_destroy(l->s);
+    for (k = 0; k < l->n_shards; k++)
+        apemost_hip_destroy(l->s[k]);
     free_view(&l->v);
     free(l);
 }
 
-apemost_hip_sampler *apemost_ladder_sampler(apemost_ladder *l) { return l->s; }
+apemost_hip_sampler *apemost_ladder_sampler(apemost_ladder *l) { return l->s[0]; }
+unsigned int apemost_ladder_shards(const apemost_ladder *l) { return l->n_shards; }
+apemost_hip_sampler *apemost_ladder_shard(apemost_ladder *l, unsigned int k) { return l->s[k]; }
+unsigned int apemost_ladder_shard_first(const apemost_ladder *l, unsigned int k) { return l->lo[k]; }
+
+/* calc_model() for chains [first, first+count) of the ladder, wherever they live */
+void apemost_ladder_calc_model(apemost_ladder *l, unsigned int first, unsigned int count) {
+    unsigned int k;
+    for (k = 0; k < l->n_shards; k++) {
+        const unsigned int a = first > l->lo[k] ? first : l->lo[k];
+        const unsigned int b = first + count < l->lo[k + 1] ? first + count : l->lo[k + 1];
+        if (a < b)
+            apemost_hip_or_die(apemost_hip_calc_model(l->s[k], (int)(a - l->lo[k]), (int)(b - a)), "calc_model");
+    }
+}
+
+/* markov_chain_calibrate() (or burn_in only) for chains [first, first+count): every shard's kernel
+ * is launched before any result is awaited, so the devices calibrate concurrently.  status[count]
+ * per chain; returns the first non-zero ABI return code (APEMOST_HIP_ERR_CALIBRATION, ...) or 0. */
+int apemost_ladder_calibrate(apemost_ladder *l, unsigned int first, unsigned int count,
+                             const apemost_hip_calib_config *c, int burn_in_only, int32_t *status) {
+    unsigned int k;
+    int rc = APEMOST_HIP_OK;
+    for (k = 0; k < l->n_shards; k++) {
+        const unsigned int a = first > l->lo[k] ? first : l->lo[k];
+        const unsigned int b = first + count < l->lo[k + 1] ? first + count : l->lo[k + 1];
+        if (a < b)
+            apemost_hip_or_die(apemost_hip_calibrate_begin(l->s[k], (int)(a - l->lo[k]), (int)(b - a), c, burn_in_only),
+                               "markov_chain_calibrate");
+    }
+    for (k = 0; k < l->n_shards; k++) {
+        const unsigned int a = first > l->lo[k] ? first : l->lo[k];
+        const unsigned int b = first + count < l->lo[k + 1] ? first + count : l->lo[k + 1];
+        if (a < b) {
+            const int r = apemost_hip_calibrate_end(l->s[k], status ? status + (a - first) : NULL, NULL);
+            if (r != APEMOST_HIP_OK && r != APEMOST_HIP_ERR_CALIBRATION)
+                apemost_hip_or_die(r, "markov_chain_calibrate");
+            if (r != APEMOST_HIP_OK && rc == APEMOST_HIP_OK)
+                rc = r;
+        }
+    }
+    return rc;
+}
+
+/* n_rounds x {n_swap steps per chain, one swap attempt} on the whole ladder (asynchronous);
+ * d_samples[k]: device rows of shard k or NULL.  n_rounds = 0 with a pending swap attempt applies
+ * just that attempt. */
+void apemost_ladder_run(apemost_ladder *l, unsigned long n_rounds, unsigned int n_swap, double **d_samples) {
+    apemost_hip_or_die(apemost_hip_run_shards(l->s, (int)l->n_shards, n_rounds, n_swap, d_samples), "run_sampler");
+}
 
 /* one-chain twin for the single-chain API; rebuilt when the data matrix or n_par changes */
 #define SINGLE_LADDER_SPAN 1048576L
@@ -395,12 +513,15 @@ apemost_ladder *apemost_single(mcmc *m) {
         cache->chains = slot;
         cache->n = 1;
         cache->n_par = m->n_par;
-        cache->s = create_sampler(m, model, 1, 0, SINGLE_LADDER_SPAN);
+        cache->n_shards = 1;
+        cache->lo[0] = 0;
+        cache->lo[1] = 1;
+        cache->s[0] = create_sampler(m, model, 1, 0, SINGLE_LADDER_SPAN, default_device());
         alloc_view(cache);
         cache_data = m->data;
     }
     slot[0] = m;
-    apemost_hip_or_die(apemost_hip_set_chain_offset(cache->s, (long)(apemost_chain_address(m)->chain_id % SINGLE_LADDER_SPAN)),
+    apemost_hip_or_die(apemost_hip_set_chain_offset(cache->s[0], (long)(apemost_chain_address(m)->chain_id % SINGLE_LADDER_SPAN)),
                        "apemost_hip_set_chain_offset");
     return cache;
 }

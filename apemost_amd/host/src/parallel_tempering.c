@@ -38,8 +38,7 @@ static void calibrate_on_device(apemost_ladder *l, unsigned int first, unsigned 
     int rc;
     unsigned int i;
     fill_calib(&c);
-    rc = apemost_hip_calibrate_chains(apemost_ladder_sampler(l), (int)first, (int)count, &c, burn_in_only, status,
-                                      NULL);
+    rc = apemost_ladder_calibrate(l, first, count, &c, burn_in_only, status);
     if (rc == APEMOST_HIP_ERR_CALIBRATION) {
         for (i = 0; i < count; i++)
             if (status[i] == 1)
@@ -49,7 +48,6 @@ static void calibrate_on_device(apemost_ladder *l, unsigned int first, unsigned 
                         first + i);
         exit(1);
     }
-    apemost_hip_or_die(rc, "markov_chain_calibrate");
     free(status);
 }
 
@@ -71,7 +69,7 @@ void calibrate_first() {
     printf("Starting markov chain calibration\n");
     fflush(stdout);
     l = apemost_ladder_open(chains, 1);
-    apemost_hip_or_die(apemost_hip_calc_model(apemost_ladder_sampler(l), 0, 1), "calc_model");
+    apemost_ladder_calc_model(l, 0, 1);
     calibrate_on_device(l, 0, 1, 0);
     apemost_ladder_download(l);
     apemost_ladder_close(l);
@@ -117,7 +115,7 @@ void calibrate_rest() {
         dump_vectorln(get_steps(chains[1]));
         fflush(stdout);
         l = apemost_ladder_open(chains, n_beta);
-        apemost_hip_or_die(apemost_hip_calc_model(apemost_ladder_sampler(l), 1, 1), "calc_model");
+        apemost_ladder_calc_model(l, 1, 1);
         calibrate_on_device(l, 1, 1, 0);
         apemost_ladder_download(l);
         apemost_ladder_close(l);
@@ -144,7 +142,7 @@ void calibrate_rest() {
         fflush(stdout);
         /* all remaining chains calibrate concurrently, one workgroup each */
         l = apemost_ladder_open(chains, n_beta);
-        apemost_hip_or_die(apemost_hip_calc_model(apemost_ladder_sampler(l), 1, (int)n_beta - 1), "calc_model");
+        apemost_ladder_calc_model(l, 1, n_beta - 1);
 #ifndef SKIP_CALIBRATE_ALLCHAINS
         calibrate_on_device(l, 1, n_beta - 1, 0);
 #else
@@ -285,43 +283,51 @@ static void sink_open(sample_sink *k, unsigned int n_beta, unsigned int n_par, u
     }
 }
 
-/* rows of iterations first+1 .. first+n_steps; h = [n_steps][n_beta][n_par+2] */
-static void sink_write(sample_sink *k, mcmc **chains, const double *h, unsigned long first, unsigned long n_steps) {
-    const unsigned int n_beta = k->n_beta, n_par = k->n_par;
-    const size_t row = (size_t)n_beta * (n_par + 2);
+/* rows of iterations first+1 .. first+n_steps.  The rows arrive per shard: h[j] =
+ * [n_steps][chains of shard j][n_par+2], shard j holding chains [lo[j], lo[j+1]) */
+static void sink_write(sample_sink *k, mcmc **chains, double *const *h, const unsigned int *lo, unsigned int n_shards,
+                       unsigned long first, unsigned long n_steps) {
+    const unsigned int n_par = k->n_par;
     /* first kept step of this batch: iteration numbers count from 1 */
     const unsigned long skip = (k->thin - (first % k->thin) - 1) % k->thin;
     unsigned long step;
-    unsigned int i, p;
+    unsigned int i, j, p;
     char name[100];
     if (k->binary) {
-        if (k->thin == 1)
-            fwrite(h, sizeof(double), n_steps * row, k->bin);
-        else
+        if (k->thin == 1 && n_shards == 1) {
+            fwrite(h[0], sizeof(double), n_steps * k->n_beta * (n_par + 2), k->bin);
+        } else {
             for (step = skip; step < n_steps; step += k->thin)
-                fwrite(h + step * row, sizeof(double), row, k->bin);
+                for (j = 0; j < n_shards; j++) {
+                    const size_t row = (size_t)(lo[j + 1] - lo[j]) * (n_par + 2);
+                    fwrite(h[j] + step * row, sizeof(double), row, k->bin);
+                }
+        }
         k->batches++;
         return;
     }
     /* chain-major: one file at a time stays hot, and ladders beyond the descriptor limit
      * (the reference asserts n_beta < 100) open, append to and close one prob file at a time */
-    for (i = 0; i < n_beta; i++) {
-        FILE *pf = k->prob_files ? k->prob_files[i] : NULL;
-        FILE **vf = chains[i]->files;
-        if (pf == NULL) {
-            sprintf(name, "prob-chain%d.dump", i);
-            pf = open_or_die(name, k->batches == 0 ? k->mode : "a");
+    for (j = 0; j < n_shards; j++) {
+        const size_t row = (size_t)(lo[j + 1] - lo[j]) * (n_par + 2);
+        for (i = lo[j]; i < lo[j + 1]; i++) {
+            FILE *pf = k->prob_files ? k->prob_files[i] : NULL;
+            FILE **vf = chains[i]->files;
+            if (pf == NULL) {
+                sprintf(name, "prob-chain%d.dump", i);
+                pf = open_or_die(name, k->batches == 0 ? k->mode : "a");
+            }
+            for (step = skip; step < n_steps; step += k->thin) {
+                const double *r = h[j] + step * row + (size_t)(i - lo[j]) * (n_par + 2);
+                if (vf != NULL)
+                    for (p = 0; p < n_par; p++)
+                        if (vf[p] != NULL)
+                            fprintf(vf[p], DUMP_FORMAT "\n", r[p]);
+                fprintf(pf, "%6e\t%6e\n", r[n_par], r[n_par + 1]);
+            }
+            if (k->prob_files == NULL)
+                fclose(pf);
         }
-        for (step = skip; step < n_steps; step += k->thin) {
-            const double *r = h + step * row + (size_t)i * (n_par + 2);
-            if (vf != NULL)
-                for (p = 0; p < n_par; p++)
-                    if (vf[p] != NULL)
-                        fprintf(vf[p], DUMP_FORMAT "\n", r[p]);
-            fprintf(pf, "%6e\t%6e\n", r[n_par], r[n_par + 1]);
-        }
-        if (k->prob_files == NULL)
-            fclose(pf);
     }
     k->batches++;
 }
@@ -364,10 +370,10 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
     sample_sink sink;
     FILE *acceptance_file;
     apemost_ladder *l;
-    apemost_hip_sampler *s;
-    double *d_samples[2] = {NULL, NULL}, *h_samples[2] = {NULL, NULL};
-    uint64_t *h_counts[2] = {NULL, NULL};
-    unsigned int i;
+    /* double-buffered per shard: device rows, pinned host rows, pinned accept/reject snapshot */
+    double *d_samples[2][APEMOST_MAX_SHARDS], *h_samples[2][APEMOST_MAX_SHARDS];
+    uint64_t *h_counts[2][APEMOST_MAX_SHARDS];
+    unsigned int lo[APEMOST_MAX_SHARDS + 1], n_shards, i, j;
     int k = 0;
 
     if (max_rounds < 1)
@@ -387,15 +393,21 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
     acceptance_file = open_or_die("acceptance_rate.dump", mode);
 
     l = apemost_ladder_open(chains, n_beta);
-    s = apemost_ladder_sampler(l);
-    for (i = 0; i < 2; i++) {
-        void *p = NULL;
-        apemost_hip_or_die(apemost_hip_samples_alloc(s, max_rounds * n_swap, &d_samples[i]), "samples_alloc");
-        apemost_hip_or_die(apemost_hip_host_alloc(max_rounds * n_swap * row * sizeof(double), &p), "host_alloc");
-        h_samples[i] = (double *)p;
-        apemost_hip_or_die(apemost_hip_host_alloc(2 * (size_t)n_beta * sizeof(uint64_t), &p), "host_alloc");
-        h_counts[i] = (uint64_t *)p;
-    }
+    n_shards = apemost_ladder_shards(l);
+    for (j = 0; j <= n_shards; j++)
+        lo[j] = apemost_ladder_shard_first(l, j);
+    for (i = 0; i < 2; i++)
+        for (j = 0; j < n_shards; j++) {
+            apemost_hip_sampler *s = apemost_ladder_shard(l, j);
+            const size_t n_local = lo[j + 1] - lo[j];
+            void *p = NULL;
+            apemost_hip_or_die(apemost_hip_samples_alloc(s, max_rounds * n_swap, &d_samples[i][j]), "samples_alloc");
+            apemost_hip_or_die(apemost_hip_host_alloc(max_rounds * n_swap * n_local * (n_par + 2) * sizeof(double), &p),
+                               "host_alloc");
+            h_samples[i][j] = (double *)p;
+            apemost_hip_or_die(apemost_hip_host_alloc(2 * n_local * sizeof(uint64_t), &p), "host_alloc");
+            h_counts[i][j] = (uint64_t *)p;
+        }
     get_duration();
     run = 1;
     dumpflag = 0;
@@ -416,21 +428,25 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
 
     PLAN_BATCH(iter, rounds_now);
     if (rounds_now > 0)
-        apemost_hip_or_die(apemost_hip_run(s, rounds_now, n_swap, d_samples[k]), "run_sampler");
+        apemost_ladder_run(l, rounds_now, n_swap, d_samples[k]);
     while (rounds_now > 0) {
         const unsigned long n_steps = rounds_now * n_swap, iter_after = iter + n_steps;
-        const uint64_t *accepts = h_counts[k], *rejects = h_counts[k] + n_beta;
-        apemost_hip_or_die(apemost_hip_samples_read_async(s, d_samples[k], n_steps, h_samples[k], h_counts[k]),
-                           "samples_read_async");
+        for (j = 0; j < n_shards; j++)
+            apemost_hip_or_die(apemost_hip_samples_read_async(apemost_ladder_shard(l, j), d_samples[k][j], n_steps,
+                                                              h_samples[k][j], h_counts[k][j]),
+                               "samples_read_async");
         PLAN_BATCH(iter_after, rounds_next);
         if (rounds_next > 0) /* the device goes on while this batch drains and is written */
-            apemost_hip_or_die(apemost_hip_run(s, rounds_next, n_swap, d_samples[k ^ 1]), "run_sampler");
-        apemost_hip_or_die(apemost_hip_samples_wait(s), "samples_wait");
-        sink_write(&sink, chains, h_samples[k], iter, n_steps);
+            apemost_ladder_run(l, rounds_next, n_swap, d_samples[k ^ 1]);
+        for (j = 0; j < n_shards; j++)
+            apemost_hip_or_die(apemost_hip_samples_wait(apemost_ladder_shard(l, j)), "samples_wait");
+        sink_write(&sink, chains, h_samples[k], lo, n_shards, iter, n_steps);
         iter = iter_after;
         apemost_swap_round += rounds_now;
         if (iter % PRINT_PROB_INTERVAL == 0) {
-            const double *last = h_samples[k] + (n_steps - 1) * row; /* chain 0's latest row */
+            /* chain 0's latest row and counters live in shard 0 */
+            const double *last = h_samples[k][0] + (n_steps - 1) * (size_t)(lo[1] - lo[0]) * (n_par + 2);
+            const uint64_t accept0 = h_counts[k][0][0], reject0 = h_counts[k][0][lo[1] - lo[0]];
             if (dumpflag) {
                 /* a report on request: the ladder as the device holds it now (a batch ahead of
                  * the rows just written when another one is already running) */
@@ -440,13 +456,13 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
                 sink_flush(&sink);
             }
             fprintf(acceptance_file, "%lu", iter);
-            for (i = 0; i < n_beta; i++)
-                fprintf(acceptance_file, "\t%lu", (unsigned long)accepts[i]);
+            for (j = 0; j < n_shards; j++)
+                for (i = 0; i < lo[j + 1] - lo[j]; i++)
+                    fprintf(acceptance_file, "\t%lu", (unsigned long)h_counts[k][j][i]);
             fprintf(acceptance_file, "\n");
             fflush(acceptance_file);
-            printf("iteration: %lu, a/r: %.3f(%lu/%lu), v:", iter,
-                   (double)accepts[0] / (double)(accepts[0] + rejects[0]), (unsigned long)accepts[0],
-                   (unsigned long)rejects[0]);
+            printf("iteration: %lu, a/r: %.3f(%lu/%lu), v:", iter, (double)accept0 / (double)(accept0 + reject0),
+                   (unsigned long)accept0, (unsigned long)reject0);
             printf("Vector%ud[", n_par); /* dump_vector's format, from the row instead of a gsl_vector */
             for (i = 0; i < n_par; i++)
                 printf("%f%s", last[i], i + 1 < n_par ? ";" : "]");
@@ -458,11 +474,12 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
     }
 #undef PLAN_BATCH
     apemost_ladder_download(l);
-    for (i = 0; i < 2; i++) {
-        apemost_hip_samples_free(s, d_samples[i]);
-        apemost_hip_host_free(h_samples[i]);
-        apemost_hip_host_free(h_counts[i]);
-    }
+    for (i = 0; i < 2; i++)
+        for (j = 0; j < n_shards; j++) {
+            apemost_hip_samples_free(apemost_ladder_shard(l, j), d_samples[i][j]);
+            apemost_hip_host_free(h_samples[i][j]);
+            apemost_hip_host_free(h_counts[i][j]);
+        }
     apemost_ladder_close(l);
     fclose(acceptance_file);
     sink_close(&sink);

@@ -8,13 +8,15 @@
 
 void tempering_interaction(mcmc **chains, unsigned int n_beta, unsigned long iter) {
     apemost_ladder *l;
+    unsigned int k;
     (void)iter;
     assert(n_beta > 0);
     if (n_beta == 1)
         return;
     l = apemost_ladder_open(chains, n_beta);
-    apemost_hip_or_die(apemost_hip_set_round(apemost_ladder_sampler(l), apemost_swap_round, 1), "set_round");
-    apemost_hip_or_die(apemost_hip_launch_round(apemost_ladder_sampler(l), 0, 1, NULL), "tempering_interaction");
+    for (k = 0; k < apemost_ladder_shards(l); k++)
+        apemost_hip_or_die(apemost_hip_set_round(apemost_ladder_shard(l, k), apemost_swap_round, 1), "set_round");
+    apemost_ladder_run(l, 0, 1, NULL); /* no steps: just the pending swap attempt */
     apemost_swap_round++;
     apemost_ladder_download(l);
     apemost_ladder_close(l);

@@ -273,6 +273,12 @@ int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t 
                                  const apemost_hip_calib_config *c, int burn_in_only,
                                  int32_t *status, uint64_t *iters);
 
+/* the same in two halves, for hosts that drive several devices from one thread: begin launches
+ * (asynchronous), end waits and collects status/iters of the chains begin named */
+int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first, int32_t count,
+                                const apemost_hip_calib_config *c, int burn_in_only);
+int apemost_hip_calibrate_end(apemost_hip_sampler *s, int32_t *status, uint64_t *iters);
+
 /* ---- test hooks: device RNG conformance ------------------------------------ */
 /* n raw 32-bit outputs of rocRAND philox4x32_10 (seed, subsequence, offset) */
 int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequence, uint64_t offset, int32_t n,

@@ -327,3 +327,78 @@ def test_library_flavour_samples_on_the_device_only_when_the_callbacks_match_a_d
                          cwd=str(tmp_path / "bad"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert bad.returncode == 1 and b"matches none of the device" in bad.stderr and b"CALIBRATED" not in bad.stdout
     assert not os.path.exists(str(tmp_path / "bad" / "calibration_results"))
+
+
+def test_c_host_with_two_shards_equals_one_device(tmp_path):
+    """APEMOST_DEVICES=0,0: the C host splits the ladder into two shards (both on this box's only GPU),
+    each with its own sampler and stream; edge records cross with hipMemcpyPeerAsync inside
+    apemost_hip_run_shards.  Every output file equals the single-shard run byte for byte."""
+    n_beta, iters = 10, 4000
+    w = wl.simplesin(n_data=128, n_chain=n_beta)
+    exe = hostlib.make(str(tmp_path / "sine.exe"),
+                       ccflags="-DN_BETA=%d -DBURN_IN_ITERATIONS=600 -DMAX_ITERATIONS=%d -DN_SWAP=5" % (n_beta, iters))
+    outs = {}
+    for name, devices in (("one", None), ("two", "0,0"), ("three", "0,0,0")):
+        work = tmp_path / name
+        _inputs(work, w)
+        env = dict(os.environ, APEMOST_SEED="12")
+        if devices:
+            env["APEMOST_DEVICES"] = devices
+        for phase in ("calibrate_first", "calibrate_rest", "run"):
+            subprocess.check_call([exe, phase], cwd=str(work), env=env, stdout=subprocess.DEVNULL)
+        outs[name] = work
+    files = ["calibration_results", "acceptance_rate.dump", "amplitude-chain-0.prob.dump", "phase-chain-0.prob.dump"] + \
+            ["prob-chain%d.dump" % i for i in range(n_beta)]
+    for name in ("two", "three"):
+        for f in files:
+            assert (outs[name] / f).read_bytes() == (outs["one"] / f).read_bytes(), (name, f)
+    assert len((outs["one"] / "prob-chain9.dump").read_text().splitlines()) == iters
+
+
+def test_run_shards_abi_equals_whole_ladder_and_oracle():
+    """apemost_hip_run_shards / apemost_hip_edge_exchange driven through ctypes: three shards on one
+    device against the whole ladder on one sampler and against the oracle"""
+    import torch
+    from apemost_amd import capi
+    from apemost_amd.sampler import HipSampler
+    from tests.helpers import assert_match, make_pair
+    w = wl.pulse(n_data=96, n_chain=11)
+    n_global, n_rounds, n_swap, seed = 11, 200, 3, 29
+    st, lad, rng = make_pair(w, n_global, seed=seed)
+    whole = HipSampler(w.model, w.n_par, n_global, w.data, seed=seed)
+    whole.set_state(st)
+    d_whole = torch.zeros((n_rounds * n_swap, n_global, w.n_par + 2), dtype=torch.float64, device="cuda")
+    whole.run_sampler(n_rounds, n_swap, d_whole.data_ptr())
+    whole.synchronize()
+    ref = whole.get_state()
+    whole.close()
+    bounds = [(0, 4), (4, 7), (7, 11)]
+    shards = []
+    for lo, hi in bounds:
+        s = HipSampler(w.model, w.n_par, hi - lo, w.data, seed=seed, chain_offset=lo, n_chains_global=n_global)
+        s.set_state(st.slice(lo, hi))
+        shards.append(s)
+    bufs = [torch.zeros((n_rounds * n_swap, hi - lo, w.n_par + 2), dtype=torch.float64, device="cuda") for lo, hi in bounds]
+    torch.cuda.synchronize()
+    handles = (C.c_void_p * 3)(*[s._h for s in shards])
+    ptrs = (C.c_void_p * 3)(*[b.data_ptr() for b in bufs])
+    L = capi.lib()
+    for part in (70, 130):                      # two calls: the swap position carries over
+        off = 0 if part == 70 else 70
+        p2 = (C.c_void_p * 3)(*[b[off * n_swap:].data_ptr() for b in bufs])
+        capi.check(L.apemost_hip_run_shards(handles, 3, part, n_swap, p2))
+    for s in shards:
+        s.synchronize()
+    got = [s.get_state() for s in shards]
+    for f in ("params", "params_best", "prob", "prob_best", "prior", "accept", "reject", "swapcount", "ticks", "n_iter"):
+        assert np.array_equal(np.concatenate([getattr(g, f) for g in got]), getattr(ref, f)), f
+    assert np.array_equal(torch.cat(bufs, dim=1).cpu().numpy(), d_whole.cpu().numpy())
+    assert ref.swapcount[3] + ref.swapcount[6] > 0          # the shard edges were crossed
+    orc_samples = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    assert_match(ref, lad, rng, what="run_shards")
+    np.testing.assert_allclose(d_whole.cpu().numpy(), orc_samples, rtol=1e-9, atol=1e-300)
+    # mismatched shards are refused
+    rc = L.apemost_hip_run_shards((C.c_void_p * 2)(shards[0]._h, shards[2]._h), 2, 1, 1, None)
+    assert rc == capi.ERR_INVALID
+    for s in shards:
+        s.close()
