@@ -12,7 +12,7 @@ import numpy as np
 from . import build as _build
 
 ABI_VERSION = 1
-FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH = 1, 2
+FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH, FLAG_TWO_BARRIER_STEP = 1, 2, 4
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_CALIBRATION = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)

@@ -1,6 +1,7 @@
 // apemost_hip.hip -- kernels and C ABI of the gfx950 parallel-tempering engine
 // (declared in include/apemost_hip.h).  Written for MI355X only.
 #include "pt_device.h"
+#include "pt_onebarrier.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -36,6 +37,8 @@ __host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? wav
 // candidate production as a side duty of waves 1-3 (workgroups of at least 4 waves)
 // (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
 __host__ __device__ constexpr bool has_producer(int waves) { return waves >= 4; }
+// the one-barrier round kernel (pt_onebarrier.h) exists for these numbers of likelihood waves
+__host__ __device__ constexpr bool has_one_barrier(int waves) { return waves == 4 || waves == 8; }
 __host__ __device__ constexpr int block_threads(int waves, bool) { return waves * kWave; }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
@@ -349,6 +352,100 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
     chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
 }
 
+// The same rounds with one barrier per step (pt_onebarrier.h): LW likelihood wavefronts plus an
+// owner and a candidate producer.  All-parameter steps only; launches with steps.
+//
+// Every role runs its own copy of the round/step loops (the registers a role carries from step to
+// step are then live in its loop only); what the copies share is the barrier sequence: one at the
+// start of a round, one per step, and one more in a step whose prepared proposal has to be redrawn
+// (every wave reads the same LDS flag for that).
+template <int MODEL, int LW, bool LDS_DATA>
+__global__ __launch_bounds__((LW + 2) * kWave) void pt_round_ob_kernel(const RoundArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    ObEngine<MODEL, LW, LDS_DATA> e;
+    const int c = blockIdx.x;
+    e.setup_common(a.d, a.sh, c, lds);
+    if (e.is_lik()) {
+        e.setup_lik(a.d, a.sh, c);
+        if (e.hw < 2)
+            e.make_set(e.tick + (u64)e.hw); // the first two ticks' candidates, by waves with nothing else to do yet
+        __syncthreads();
+        e.cache_rows();
+        for (unsigned r = 0; r < a.n_rounds; r++) {
+            __syncthreads();
+            for (unsigned s = 0; s < a.n_steps; s++) {
+                const int p = (int)(s & 1);
+                if (e.redraw_pending(p))
+                    __syncthreads();
+                e.lik_step(p);
+                __syncthreads();
+            }
+        }
+    } else if (e.is_producer()) {
+        e.setup_lanes(a.sh);
+        e.producer_prologue();
+        __syncthreads();
+        for (unsigned r = 0; r < a.n_rounds; r++) {
+            __syncthreads();
+            for (unsigned s = 0; s < a.n_steps; s++) {
+                if (e.redraw_pending((int)(s & 1)))
+                    __syncthreads();
+                e.producer_step(e.tick);
+                e.tick++;
+                __syncthreads();
+            }
+        }
+    } else {
+        e.setup_lanes(a.sh);
+        e.setup_owner(a.d, a.sh, c);
+        chain_load(e, a.d, a.sh, c, a.cur);
+        e.thr_fn.init(e.consts, e.beta_all);
+        SwapMemo memo;
+        memo.partner0 = memo.partner1 = -1;
+        memo.index0 = memo.index1 = 0;
+        if (a.apply_swap)
+            swap_at_launch_start(e, a.d, a.sh, c, a.cur, a.round, memo);
+        __syncthreads();
+        const int n = a.sh.n_par;
+        double *my_sample = nullptr;
+        if (a.samples && (e.lane == 63 || (e.cand() && e.qidx == 0)))
+            my_sample = a.samples + (size_t)c * (n + 2) + (e.lane == 63 ? n : e.grp);
+        const size_t sample_stride = (size_t)a.sh.n_chains * (n + 2);
+        for (unsigned r = 0; r < a.n_rounds; r++) {
+            if (r > 0) // the swap attempt between round r-1 and round r; the other waves wait at the barrier below
+                swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
+            e.owner_first();
+            __syncthreads();
+            for (unsigned s = 0; s < a.n_steps; s++) {
+                const int p = (int)(s & 1);
+                const bool redraw_pending = e.redraw_pending(p);
+                if (s > 0) {
+                    e.owner_results(p, my_sample);
+                    if (my_sample)
+                        my_sample += sample_stride;
+                }
+                e.owner_choose(p, s == 0);
+                if (redraw_pending) // rare: a proposal in LDS has just been replaced
+                    __syncthreads();
+                e.owner_publish(p);
+                e.tick++;
+                __syncthreads();
+            }
+            if (a.n_steps > 0) { // the last step of the round
+                e.owner_results((int)(a.n_steps & 1), my_sample);
+                if (my_sample)
+                    my_sample += sample_stride;
+            }
+        }
+        if (e.lane == 0)
+            a.d.n_iter()[c] += (u64)a.n_steps * a.n_rounds;
+        wait_for_reader<decltype(e)>(a.d, a.sh, memo, a.cur ^ 1);
+        if (e.lane == 0 && *e.fail_flag())
+            st_agent(a.d.timeout_word(), 3);
+        chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
+    }
+}
+
 // calc_model() for every resident chain, in place
 template <int MODEL, int WAVES, bool LDS_DATA>
 __global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const RoundArgs a) {
@@ -359,6 +456,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const Round
     e.m.clear_box(); // caller-supplied parameters may lie outside their prior box
     chain_load(e, a.d, a.sh, c, a.cur);
     __syncthreads();
+    e.cache_rows();
     e.calc_model_current();
     if (e.wave == 0 && e.lane == 0) {
         a.d.prob(a.cur)[c + 1] = e.prob;
@@ -392,6 +490,7 @@ __global__ __launch_bounds__(WAVES *kWave) void pt_loglike_kernel(const EvalArgs
     e.prior = 0;
     e.cur = (e.wave == 0 && e.cand()) ? a.params[(size_t)c * a.sh.n_par + e.grp] : 0.0;
     __syncthreads();
+    e.cache_rows();
     e.calc_model_current();
     if (e.wave == 0 && e.lane == 0) {
         a.prob[c] = e.prob;
@@ -675,6 +774,7 @@ struct apemost_hip_sampler {
     hipStream_t copy_stream; // drains sample rows while the next launch runs (created on first use)
     hipEvent_t ev_copy;
     u64 *h_word;             // pinned copy of the launch error word, refreshed by every async read
+    bool one_barrier;    // stepping launches use pt_round_ob_kernel
     bool cooperative;    // multi-round launches through hipLaunchCooperativeKernel
     bool handoff_failed; // an in-launch hand-off timed out once: single-round launches from then on
 };
@@ -721,7 +821,8 @@ extern "C" int apemost_hip_device_info(int device, char *name, size_t name_len, 
 
 static int enable_big_lds(apemost_hip_sampler *s);
 template <bool LDS>
-static hipError_t round_occupancy(int model, int waves, bool producers, size_t lds_bytes, int *blocks);
+static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks);
+static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data);
 
 template <class T>
 static int dev_alloc(apemost_hip_sampler *s, T **p, size_t count) {
@@ -800,7 +901,8 @@ static int create_body(apemost_hip_sampler *s) {
         return fail(APEMOST_HIP_ERR_INVALID, "waves_per_chain must be 1, 2, 4, 6 or 8");
     const size_t fixed_lds = (kFixedLdsDoubles + (size_t)cand_slots(s->waves) * 2 * kWave) * sizeof(double);
     const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
-    s->lds_data = fixed_lds + data_lds <= 160 * 1024 - 1024 && cfg->lds_policy != 2 &&
+    const size_t fixed_max = fixed_lds > kObFixedDoubles * sizeof(double) ? fixed_lds : kObFixedDoubles * sizeof(double);
+    s->lds_data = fixed_max + data_lds <= 160 * 1024 - 1024 && cfg->lds_policy != 2 &&
                   (cfg->lds_policy == 1 || choose_lds(*cfg, fixed_lds + data_lds));
     s->lds_bytes = fixed_lds + (s->lds_data ? data_lds : 0);
     s->lds_fixed_bytes = fixed_lds;
@@ -836,10 +938,15 @@ static int create_body(apemost_hip_sampler *s) {
         // heavy kernels: MI355X_MICROARCH.md "Residency and cooperative launch").
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+        // the round kernel this sampler's stepping launches use: one barrier per step where that
+        // variant exists (4 or 8 likelihood waves per chain), the classic two-phase step otherwise
+        s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
         int b_lds = 0, b_plain = 0;
         if (s->lds_data)
-            HIP_TRY(round_occupancy<true>(cfg->model, s->waves, s->producers, s->lds_bytes, &b_lds));
-        HIP_TRY(round_occupancy<false>(cfg->model, s->waves, s->producers, s->lds_fixed_bytes, &b_plain));
+            HIP_TRY(round_occupancy<true>(cfg->model, s->waves, s->producers, s->one_barrier,
+                                          s->one_barrier ? ob_lds_bytes(s, true) : s->lds_bytes, &b_lds));
+        HIP_TRY(round_occupancy<false>(cfg->model, s->waves, s->producers, s->one_barrier,
+                                       s->one_barrier ? ob_lds_bytes(s, false) : s->lds_fixed_bytes, &b_plain));
         const long long cus = prop.multiProcessorCount;
         s->resident_lds = s->lds_data && (long long)cfg->n_chains <= (long long)(b_lds - 1) * cus;
         s->resident_plain = (long long)cfg->n_chains <= (long long)(b_plain - 1) * cus;
@@ -873,7 +980,8 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
                     (long long)cfg->n_chains_global);
     if (cfg->n_par < 64 && (cfg->circular_params >> cfg->n_par) != 0)
         return fail(APEMOST_HIP_ERR_INVALID, "circular_params names a parameter beyond n_par");
-    if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH))
+    if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH |
+                       APEMOST_HIP_FLAG_TWO_BARRIER_STEP))
         return fail(APEMOST_HIP_ERR_INVALID, "unknown bits in flags: 0x%x", (unsigned)cfg->flags);
     if (cfg->n_chains_global > 2000000)
         return fail(APEMOST_HIP_ERR_INVALID, "n_beta*1000 must fit an int (interaction.c:92)");
@@ -1114,7 +1222,7 @@ extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, in
 }
 
 // ---- launch dispatch over (model, waves, lds) ----
-enum KernelKind { K_ROUND, K_CALC, K_EVAL, K_CALIB };
+enum KernelKind { K_ROUND, K_ROUND_OB, K_CALC, K_EVAL, K_CALIB };
 
 template <int MODEL, int WAVES, bool LDS>
 static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int grid, size_t lds, hipStream_t st,
@@ -1137,6 +1245,19 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
             hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
         else
             hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, false>), g, b, lds, st, *(const RoundArgs *)args);
+        break;
+    case K_ROUND_OB:
+        if constexpr (has_one_barrier(WAVES)) {
+            const dim3 bo((WAVES + 2) * kWave); // + owner + candidate producer
+            if (coop) {
+                void *params[] = {const_cast<void *>(args)};
+                return hipLaunchCooperativeKernel((const void *)pt_round_ob_kernel<MODEL, WAVES, LDS>, g, bo, params,
+                                                  (unsigned int)lds, st);
+            }
+            hipLaunchKernelGGL((pt_round_ob_kernel<MODEL, WAVES, LDS>), g, bo, lds, st, *(const RoundArgs *)args);
+        } else {
+            return hipErrorInvalidDeviceFunction;
+        }
         break;
     case K_CALC:
         hipLaunchKernelGGL((pt_calc_model_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
@@ -1228,6 +1349,10 @@ struct LaunchOp {
     }
 };
 
+static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data) {
+    return (size_t)kObFixedDoubles * sizeof(double) + (lds_data ? (size_t)2 * s->cfg.n_data * sizeof(double) : 0);
+}
+
 // stage_data: a launch that walks the data vector only a few times (n_swap < 4, single
 // likelihood evaluations) reads it through L2 instead of copying it into LDS first
 static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true,
@@ -1238,7 +1363,7 @@ static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void 
     op.producers = s->producers;
     op.coop = coop;
     op.grid = grid;
-    op.lds = op.lds_data ? s->lds_bytes : s->lds_fixed_bytes;
+    op.lds = kind == K_ROUND_OB ? ob_lds_bytes(s, op.lds_data) : op.lds_data ? s->lds_bytes : s->lds_fixed_bytes;
     op.st = s->stream;
     op.args = args;
     const hipError_t err = dispatch(s->cfg.model, s->waves, op);
@@ -1334,6 +1459,12 @@ static hipError_t set_lds_attr(size_t bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
         return e;
+    if constexpr (has_one_barrier(WAVES)) {
+        e = hipFuncSetAttribute((const void *)pt_round_ob_kernel<MODEL, WAVES, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes + 2048);
+        if (e != hipSuccess)
+            return e;
+    }
     return hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1350,11 +1481,17 @@ struct LdsAttrOp {
 template <bool LDS>
 struct OccupancyOp {
     bool producers;
+    bool one_barrier;
     size_t lds_bytes;
     int *blocks;
     template <int MODEL, int WAVES>
     hipError_t run() const {
         constexpr bool kCanProduce = has_producer(WAVES);
+        if constexpr (has_one_barrier(WAVES)) {
+            if (one_barrier)
+                return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS>,
+                                                                    (WAVES + 2) * kWave, lds_bytes);
+        }
         if (kCanProduce && producers)
             return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
                                                                 block_threads(WAVES, true), lds_bytes);
@@ -1364,9 +1501,10 @@ struct OccupancyOp {
 };
 
 template <bool LDS>
-static hipError_t round_occupancy(int model, int waves, bool producers, size_t lds_bytes, int *blocks) {
+static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks) {
     OccupancyOp<LDS> op;
     op.producers = producers;
+    op.one_barrier = one_barrier;
     op.lds_bytes = lds_bytes;
     op.blocks = blocks;
     return dispatch(model, waves, op);
@@ -1443,7 +1581,8 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     bool stage = (u64)n_steps * n_rounds >= 4 || s->cfg.lds_policy == 1;
     if (n_rounds > 1) // residency decides when workgroups wait for each other
         stage = s->resident_lds ? stage || !s->resident_plain : false;
-    rc = launch(s, K_ROUND, s->cfg.n_chains, &a, stage, s->cooperative && n_rounds > 1);
+    const bool one_barrier = s->one_barrier && which < 0 && n_steps > 0;
+    rc = launch(s, one_barrier ? K_ROUND_OB : K_ROUND, s->cfg.n_chains, &a, stage, s->cooperative && n_rounds > 1);
     if (rc && s->cooperative && n_rounds > 1) {
         // the runtime cannot place the grid at once: single-round launches from now on
         s->resident_ok = false;

@@ -1,0 +1,494 @@
+// pt_onebarrier.h -- the round kernel for ladders of few chains: one barrier per Metropolis step.
+//
+// When a ladder has fewer chains than the chip has CUs (BASELINE config 2: 128 chains), a chain's
+// step is a latency chain and the throughput is chains / step latency.  The step of pt_device.h's
+// Engine is two phases separated by two barriers: every wave evaluates its slice of the data
+// vector (A -> B), then wave 0 alone adds the partial sums, finishes the likelihood, runs the
+// accept test, the bookkeeping and the next proposal, and hands the proposal to the other waves
+// through LDS (B -> A); the second phase is ~1300 of the ~2300 cycles of a step
+// (profiles/r02_c2_stamps.txt).
+//
+// Here the serial phase is taken off the critical path:
+//
+//   * The accept test (src/markov_chain.c:282-311) becomes ONE comparison on the raw data sum.
+//     accept <=> prob_new >= prob or ln U < prob_new - prob <=> prob_new > prob + ln U (ln U < 0),
+//     and prob_new is a decreasing function of the data sum S, so accept <=> S < S_max where
+//     S_max is computed from (prob, ln U, the proposal's prior) while the likelihood is still
+//     being evaluated.  The two forms differ only when prob_new - prob and ln U agree to ~1 ulp.
+//   * Both possible next proposals are prepared ahead: the proposal of step t+1 starts from the
+//     proposal of step t if that is accepted and from the current point if not, and everything
+//     else it needs (the Gaussian candidates of tick t+1, the step widths, the prior box) is known
+//     while step t's likelihood runs.  Both variants are published in LDS before the barrier.
+//   * After the barrier EVERY wave adds the partial sums itself, compares with S_max, selects its
+//     variant of the proposal and goes straight into the next likelihood.  No second barrier, no
+//     hand-over.
+//
+// Roles in a workgroup of LW + 2 wavefronts: waves 0..LW-1 evaluate the likelihood; wave LW (the
+// owner) keeps the chain: counters, current point, best point, sample rows, thresholds and the
+// speculative proposals -- all one step behind the likelihood waves, in their shadow; wave LW+1
+// produces the Gaussian candidates (Philox block, polar test, logarithm, division, square root),
+// one set per step, three ticks in flight.
+//
+// Draws, proposals, sums (same tree order as Engine with the same number of likelihood waves) and
+// recorded values are those of Engine; only the form of the accept comparison differs.
+#pragma once
+
+#include "pt_device.h"
+
+namespace apemost {
+
+// LDS carve (doubles); [2] = parity of the step that published the entry
+constexpr int kObPart = 0;                        // [2][16] wave partials of the data sum
+constexpr int kObThr = 32;                        // [2]     S_max of the step the partials belong to
+constexpr int kObFlag = 34;                       // [2]     != 0: a prepared proposal needs the redraw path
+constexpr int kObCtl = 36;                        // 4 control words (word 2 of the int view: Engine's fail flag slot)
+constexpr int kObProp = 40;                       // [2][2][64] proposals: [parity][0 = after accept, 1 = after reject][parameter]
+constexpr int kObCand = kObProp + 2 * 2 * kWave;  // [8][64] double2 candidate ring
+constexpr int kObFixedDoubles = kObCand + 8 * 2 * kWave;
+
+// S_max of a step: accept <=> data sum < S_max.  T = prob + ln U.
+template <int MODEL>
+struct ObThreshold;
+
+template <>
+struct ObThreshold<APEMOST_MODEL_SIMPLESIN> {
+    double denom_over_beta; // (-2 sigma^2) / beta < 0
+    __device__ __forceinline__ void init(const ModelConsts &c, double beta) {
+        denom_over_beta = (-2 * c.sigma * c.sigma) / beta;
+    }
+    // prob_new = beta S / denom > T  <=>  S < T denom / beta
+    template <class M>
+    __device__ __forceinline__ double s_max(double T, const M &m, double, double) const {
+        const double s = T * denom_over_beta;
+        return m.nan_hi ? -__builtin_inf() : s; // an argument outside the sine's range: prob_new is NaN, never accepted
+    }
+};
+template <>
+struct ObThreshold<APEMOST_MODEL_SINE3> : ObThreshold<APEMOST_MODEL_SIMPLESIN> {};
+
+template <>
+struct ObThreshold<APEMOST_MODEL_PULSE> {
+    double inv_beta;
+    __device__ __forceinline__ void init(const ModelConsts &, double beta) { inv_beta = 1.0 / beta; }
+    // prob_new = prior + -beta (p1 + S) > T  <=>  S < (prior - T) / beta - p1
+    template <class M>
+    __device__ __forceinline__ double s_max(double T, const M &, double prior_new, double p1) const {
+        return (prior_new - T) * inv_beta - p1;
+    }
+};
+template <>
+struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> {};
+
+template <int MODEL, int LW, bool LDS_DATA>
+struct ObEngine {
+    static constexpr int kLikThreads = LW * kWave;
+    static constexpr int kBlock = (LW + 2) * kWave;
+    static constexpr int kWide = LW < 8 ? 4 : 2;
+    static constexpr bool kShortChain = LW >= 4;
+    static constexpr bool kSine = MODEL == APEMOST_MODEL_SIMPLESIN || MODEL == APEMOST_MODEL_SINE3;
+
+    // ---- identity ----
+    int lane, hw;  // lane, hardware wave index in the workgroup
+    int wave;      // 0 = owner: the name and value the shared chain_load / chain_store / swap helpers test
+    int tid;       // likelihood thread index (likelihood waves)
+    __device__ __forceinline__ bool is_lik() const { return hw < LW; }
+    __device__ __forceinline__ bool is_owner() const { return hw == LW; }
+    __device__ __forceinline__ bool is_producer() const { return hw == LW + 1; }
+
+    int n_par, n_data;
+    int Q, grp, qidx, n_cand_lanes;
+    u64 grpmask, lowmask;
+    __device__ __forceinline__ bool cand() const { return lane < n_cand_lanes; }
+    ModelConsts consts;
+    u64 circular, seed, g;
+    const double *xs, *ys;
+    double *lds;
+    u64 tick; // tick of the step in flight (uniform in the workgroup)
+    double beta_all, x_abs_max;
+    Model<MODEL> m;
+    ObThreshold<MODEL> thr_fn;
+
+    // ---- owner: the chain (same meaning as Engine's fields) ----
+    double cur, best, stepw, lo, hi;
+    u64 pacc, prej;
+    double prob, prior, prob_best;
+    u64 accept, reject;
+    double par_val;     // the step in flight proposes this value for my parameter
+    double thr;         // S_max of the step in flight
+    u64 fail_a, fail_r; // parameter groups whose prepared attempts all failed, per variant
+    double cand_y, cand_s, next_y, next_s; // candidates of the tick in flight / of the next one
+
+    // ---- likelihood waves: data rows kept in registers when the vector is one pass ----
+    bool rows_in_regs;
+    double row_x[kWide], row_y[kWide];
+
+    __device__ __forceinline__ double *s_part(int parity) const { return lds + kObPart + parity * 16; }
+    __device__ __forceinline__ double *s_thr(int parity) const { return lds + kObThr + parity; }
+    __device__ __forceinline__ int *s_flag(int parity) const { return (int *)(lds + kObFlag + parity); }
+    // uniform by construction (every lane reads the same word): say so, the branch on it guards a barrier
+    __device__ __forceinline__ bool redraw_pending(int parity) const {
+        return __builtin_amdgcn_readfirstlane(*s_flag(parity)) != 0;
+    }
+    __device__ __forceinline__ double *s_prop(int parity, int variant) const {
+        return lds + kObProp + (parity * 2 + variant) * kWave;
+    }
+    __device__ __forceinline__ double2 *s_cand(u64 t) const { return (double2 *)(lds + kObCand) + (int)(t & 7) * kWave; }
+    __device__ __forceinline__ volatile int *fail_flag() const { return (volatile int *)(lds + kObCtl) + 2; }
+
+    // every wave: who am I, where is the data; stages the data vector (all threads copy)
+    __device__ __forceinline__ void setup_common(const DevArrays &d, const ChainShape &sh, int c, double *lds_) {
+        lane = threadIdx.x & (kWave - 1);
+        hw = threadIdx.x / kWave;
+        wave = hw == LW ? 0 : hw + 1;
+        tid = hw * kWave + lane;
+        n_par = sh.n_par;
+        n_data = sh.n_data;
+        lds = lds_;
+        tick = d.ticks()[c];
+        if (threadIdx.x == 0) {
+            *fail_flag() = 0;
+            *s_flag(0) = 0;
+            *s_flag(1) = 0;
+        }
+        double *s_data = lds + kObFixedDoubles;
+        if (LDS_DATA) {
+            for (int i = threadIdx.x; i < 2 * sh.n_data; i += kBlock)
+                s_data[i] = d.data[i];
+            xs = s_data;
+            ys = s_data + sh.n_data;
+        } else {
+            xs = d.data;
+            ys = d.data + sh.n_data;
+        }
+    }
+    // owner and producer: the (parameter, attempt) lane layout and the RNG address
+    __device__ __forceinline__ void setup_lanes(const ChainShape &sh) {
+        circular = sh.circular;
+        seed = sh.seed;
+        g = (u64)(sh.chain_offset + blockIdx.x);
+        Q = 63 / n_par;
+        grp = lane / Q;
+        qidx = lane - grp * Q;
+        n_cand_lanes = n_par * Q;
+        lowmask = grpmask = ~0ull;
+        if (cand()) {
+            grpmask = ((1ull << Q) - 1ull) << (grp * Q);
+            lowmask = grpmask & ((1ull << lane) - 1ull);
+        } else {
+            grp = 0;
+            qidx = 1 << 30;
+        }
+    }
+    __device__ __forceinline__ void setup_lik(const DevArrays &, const ChainShape &sh, int) {
+        setup_lanes(sh); // (the first two candidate sets are made by likelihood waves)
+        consts = sh.consts;
+        x_abs_max = sh.x_abs_max;
+        rows_in_regs = false;
+        m.init();
+        m.set_consts(consts);
+    }
+    __device__ __forceinline__ void setup_owner(const DevArrays &d, const ChainShape &sh, int c) {
+        consts = sh.consts;
+        x_abs_max = sh.x_abs_max;
+        fail_a = fail_r = 0;
+        cand_y = cand_s = next_y = next_s = 0;
+        par_val = thr = 0;
+        accepted = false;
+        m.init_scalar();
+        m.set_consts(consts);
+        m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
+    }
+
+    // ---- candidates (same arithmetic as Engine::cand_begin / cand_finish) ----
+    struct Half {
+        double y, v; // attempt lanes: second polar coordinate and r^2; lane 63: (unused, the uniform)
+        bool ok;
+    };
+    __device__ __forceinline__ Half cand_begin(u64 t) const {
+        Half h;
+        h.y = h.v = 0;
+        h.ok = false;
+        if (cand()) {
+            const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)grp, (t << kTickShift) | (u64)qidx);
+            const double x = -1 + 2 * u32_to_uniform(b.x);
+            h.y = -1 + 2 * u32_to_uniform(b.y);
+            h.v = x * x + h.y * h.y;
+            h.ok = b.x != 0 && b.y != 0 && !(h.v > 1.0 || h.v == 0);
+        } else if (lane == 63) {
+            const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)n_par, t << kTickShift);
+            h.v = u32_to_uniform(b.x);
+        }
+        return h;
+    }
+    // ln r^2 for the attempt lanes, ln u for lane 63 (one field for both: a select between two
+    // fields of a struct turns into a computed address and the whole engine into scratch memory)
+    __device__ __forceinline__ double cand_log(const Half &h) const { return log(h.v); }
+    __device__ __forceinline__ double2 cand_end(const Half &h, double lg) const {
+        double2 c;
+        c.x = c.y = 0;
+        if (cand()) {
+            const double sq = sqrt(-2.0 * lg / h.v);
+            c.x = h.y;
+            c.y = h.ok ? sq : __builtin_nan("");
+        } else if (lane == 63) {
+            c.x = lg;
+        }
+        return c;
+    }
+    __device__ __forceinline__ void make_set(u64 t) {
+        const Half h = cand_begin(t);
+        s_cand(t)[lane] = cand_end(h, cand_log(h));
+    }
+
+    // producer pipeline: set t+2 leaves, set t+3 gets its logarithm, set t+4 its Philox block
+    Half pipe_b, pipe_c;
+    double log_c;
+    // before the kernel's first barrier (likelihood waves 0 and 1 make the sets of ticks t0 and
+    // t0+1 meanwhile): the pipeline filled for t0+2 and t0+3
+    __device__ __forceinline__ void producer_prologue() {
+        pipe_c = cand_begin(tick + 2);
+        log_c = cand_log(pipe_c);
+        pipe_b = cand_begin(tick + 3);
+    }
+    __device__ __forceinline__ void producer_step(u64 t) {
+        const Half a = cand_begin(t + 4);
+        const double lb = cand_log(pipe_b);
+        s_cand(t + 2)[lane] = cand_end(pipe_c, log_c);
+        pipe_c = pipe_b;
+        log_c = lb;
+        pipe_b = a;
+    }
+
+    // ---- the partial sums of a step, added in Engine's order ----
+    __device__ __forceinline__ double tree(int parity) const {
+        double part[LW];
+        const double *sp = s_part(parity);
+#pragma unroll
+        for (int w = 0; w < LW; w++)
+            part[w] = sp[w];
+#pragma unroll
+        for (int span = 1; span < LW; span *= 2) {
+#pragma unroll
+            for (int w = 0; w + span < LW; w += 2 * span)
+                part[w] += part[w + span];
+        }
+        return part[0];
+    }
+
+    // ---- likelihood waves ----
+    __device__ __forceinline__ void cache_rows() {
+        rows_in_regs = n_data == kWide * kLikThreads;
+#pragma unroll
+        for (int j = 0; j < kWide; j++) {
+            row_x[j] = rows_in_regs ? xs[tid + j * kLikThreads] : 0.0;
+            row_y[j] = rows_in_regs ? ys[tid + j * kLikThreads] : 0.0;
+        }
+    }
+
+    // the wave's share of sum_i term(x_i, y_i) at the loaded parameters (Engine::reduce_data's loops)
+    __device__ __forceinline__ double lik_partial() {
+        double acc = 0;
+        int i = tid;
+        if (rows_in_regs) {
+            double tw[kWide];
+            m.template terms<kWide, kShortChain>(row_x, row_y, tw);
+#pragma unroll
+            for (int j = 0; j < kWide; j++)
+                acc += tw[j];
+            i = n_data;
+        }
+        if (LW < 8) {
+            for (; i + 3 * kLikThreads < n_data; i += 4 * kLikThreads) {
+                const double x4[4] = {xs[i], xs[i + kLikThreads], xs[i + 2 * kLikThreads], xs[i + 3 * kLikThreads]};
+                const double y4[4] = {ys[i], ys[i + kLikThreads], ys[i + 2 * kLikThreads], ys[i + 3 * kLikThreads]};
+                double t4[4];
+                m.template terms<4, kShortChain>(x4, y4, t4);
+                acc += t4[0];
+                acc += t4[1];
+                acc += t4[2];
+                acc += t4[3];
+            }
+        }
+        for (; i + kLikThreads < n_data; i += 2 * kLikThreads) {
+            const double x2[2] = {xs[i], xs[i + kLikThreads]};
+            const double y2[2] = {ys[i], ys[i + kLikThreads]};
+            double t2[2];
+            m.template terms<2, kShortChain>(x2, y2, t2);
+            acc += t2[0];
+            acc += t2[1];
+        }
+        for (; i < n_data; i += kLikThreads)
+            acc += m.term(xs[i], ys[i]);
+        return wave_allreduce_sum(acc);
+    }
+
+    // One step of a likelihood wave.  `parity` holds what the previous step published: its partial
+    // sums and threshold, and the two prepared proposals of this step.
+    __device__ __forceinline__ void lik_step(int parity) {
+        // everything the decision needs is requested at once: the partial sums, the threshold and
+        // BOTH prepared proposals (selecting the row first and reading it afterwards would put a
+        // second LDS round trip on the critical path)
+        double part[LW];
+        const double *sp = s_part(parity);
+#pragma unroll
+        for (int w = 0; w < LW; w++)
+            part[w] = sp[w];
+        const double limit = *s_thr(parity);
+        m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
+#pragma unroll
+        for (int span = 1; span < LW; span *= 2) {
+#pragma unroll
+            for (int w = 0; w + span < LW; w += 2 * span)
+                part[w] += part[w + span];
+        }
+        m.pick2(part[0] < limit, n_par);
+        const double mine = lik_partial();
+        if (lane == 0)
+            s_part(parity ^ 1)[hw] = mine;
+    }
+
+    // ---- owner ----
+    // proposal attempts of the tick whose candidates are (cy, cs), from base point `from`:
+    // first usable attempt per parameter -> LDS row `row`; returns the groups where none was usable
+    __device__ __forceinline__ u64 attempts(double from, double cy, double cs, double *row) const {
+        double prop = from + stepw * cy * cs;
+        bool inside = !(prop > hi || prop < lo);
+        if (circular != 0) {
+            const bool wrap = !inside && ((circular >> grp) & 1);
+            if (wrap)
+                prop = wrap_circular(prop, lo, hi);
+            inside = inside || wrap;
+        }
+        const bool ok = cand() && (cs == cs) && inside;
+        const u64 mask = __ballot(ok);
+        if (ok && (mask & lowmask) == 0)
+            row[grp] = prop;
+        return __ballot(cand() && qidx == 0 && (mask & grpmask) == 0);
+    }
+    // Engine::propose's rare path: none of the Q prepared attempts of a parameter worked -> the
+    // whole wave tries 64 more at a time (attempt indices continue at Q, as in the serial loop of
+    // src/markov_chain.c:235-240)
+    __device__ __forceinline__ void redraw(u64 failed, u64 t, double *row) {
+        while (failed) {
+            const int leader = __builtin_ctzll(failed);
+            const int p = leader / Q;
+            const double c0 = read_lane(cur, leader), w0 = read_lane(stepw, leader);
+            const double lo0 = read_lane(lo, leader), hi0 = read_lane(hi, leader);
+            for (unsigned qbase = (unsigned)Q;; qbase += kWave) {
+                if (qbase >= (1u << kTickShift) - kWave) {
+                    if (lane == 0) {
+                        row[p] = c0;
+                        *fail_flag() = 1;
+                    }
+                    break;
+                }
+                double y, s;
+                const bool v = gaussian_attempt(seed, g, p, t, (u64)(qbase + (unsigned)lane), y, s);
+                double pr = c0 + w0 * y * s;
+                bool inside = !(pr > hi0 || pr < lo0);
+                if (!inside && ((circular >> p) & 1)) {
+                    pr = wrap_circular(pr, lo0, hi0);
+                    inside = true;
+                }
+                const u64 m2 = __ballot(v && inside);
+                if (m2) {
+                    if (lane == __builtin_ctzll(m2))
+                        row[p] = pr;
+                    break;
+                }
+            }
+            failed &= failed - 1;
+        }
+    }
+
+    // round start: the proposal of the first step from the current point (nothing to speculate on),
+    // published as both variants; no partial sums yet, so the threshold slot says "take either"
+    __device__ __forceinline__ void owner_first() {
+        const double2 c0 = s_cand(tick)[lane];
+        cand_y = c0.x;
+        cand_s = c0.y;
+        double *row = s_prop(0, 1);
+        const u64 failed = attempts(cur, cand_y, cand_s, row);
+        redraw(failed, tick, row);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_par)
+            s_prop(0, 0)[lane] = row[lane];
+        if (lane == 0) {
+            *s_thr(0) = __builtin_inf();
+            *s_flag(0) = 0;
+        }
+        if (lane < LW)
+            s_part(0)[lane] = 0;
+        fail_a = fail_r = 0;
+    }
+
+    // results of the step that just finished (tick - 1 from now on): check_accept through the
+    // threshold, counters, mcmc_check_best, the sample row; then the rare redraw of the chosen variant
+    bool accepted; // outcome of the step just finished (uniform)
+    __device__ __forceinline__ void owner_results(int parity, double *sample) {
+        const double sum = tree(parity);
+        accepted = sum < thr;
+        double prior_new = prior;
+        const double prob_new = m.finish(sum, beta_all, consts, &prior_new);
+        if (Model<MODEL>::kHasPrior)
+            prior = prior_new; // not restored on reject (quirk Q7)
+        accept += accepted ? 1u : 0u;
+        reject += accepted ? 0u : 1u;
+        pacc += accepted ? 1u : 0u;
+        prej += accepted ? 0u : 1u;
+        if (accepted) {
+            if (cand())
+                cur = par_val;
+            prob = prob_new;
+        }
+        if (prob > prob_best) { // mcmc_check_best
+            prob_best = prob;
+            best = cur;
+        }
+        if (sample) {
+            if (lane == 63) {
+                sample[0] = prob;
+                sample[1] = prob - prior;
+            } else {
+                sample[0] = cur;
+            }
+        }
+        cand_y = next_y; // the kernel's loop has advanced `tick` to the step now in flight
+        cand_s = next_s;
+    }
+
+    // the step now in flight proposes s_prop(parity, variant): settle it (redraw path if the
+    // prepared attempts of the chosen variant failed), keep its value, publish its threshold and the
+    // two prepared proposals of the step after it into the other parity
+    __device__ __forceinline__ void owner_choose(int parity, bool first) {
+        double *row = s_prop(parity, (first || accepted) ? 0 : 1);
+        const u64 failed = first ? 0 : (accepted ? fail_a : fail_r);
+        if (failed) // (the workgroup takes an extra barrier after this: s_flag(parity) is set)
+            redraw(failed, tick, row);
+        __builtin_amdgcn_wave_barrier();
+        par_val = cand() ? row[grp] : 0.0;
+        m.load(row, n_par, x_abs_max);
+    }
+    __device__ __forceinline__ void owner_publish(int parity) {
+        const int next = parity ^ 1;
+        // candidates of the next tick: published by the barrier that opened this step
+        const double2 nx = s_cand(tick + 1)[lane];
+        next_y = nx.x;
+        next_s = nx.y;
+        // S_max of the step in flight
+        double prior_new = 0;
+        if (Model<MODEL>::kHasPrior)
+            prior_new = m.prior_only(consts);
+        const double lu = read_lane(cand_y, 63);
+        thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());
+        if (lane == 0)
+            *s_thr(next) = thr;
+        // the two proposals of the next step: from the proposal in flight, from the current point
+        fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0));
+        fail_r = attempts(cur, next_y, next_s, s_prop(next, 1));
+        if (lane == 0)
+            *s_flag(next) = (fail_a | fail_r) != 0 ? 1 : 0;
+    }
+};
+
+} // namespace apemost

@@ -171,7 +171,7 @@ def test_config5_shard_size_with_device_calibration():
         status, iters = s.markov_chain_calibrate(0, n_local, dcfg)
         cal = s.get_state()
         d = torch.zeros((4, n_local, 9), dtype=torch.float64, device="cuda")
-        s.run_sampler(4, 1, d.data_ptr())
+        s.launch_round(4, False, d.data_ptr())      # a shard: four steps, no swap attempt in between
         s.synchronize()
         outs.append((status, iters, cal, s.get_state(), d.cpu().numpy()))
         s.close()

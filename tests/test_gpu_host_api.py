@@ -78,6 +78,7 @@ def test_single_chain_api_matches_oracle(tmp_path, monkeypatch):
     lib = hostlib.make(str(tmp_path / "libsine.so"), app=SINE, ccflags="-DN_BETA=4", shared=True)
     L = hostlib.load(lib)
     w = wl.simplesin(n_data=200, n_chain=4)
+    w.step = w.step * 0.05                            # narrow enough for the cold posterior to accept some
     params, data = _inputs(tmp_path / "w", w)
     data_m = np.loadtxt(data.decode())
     m = L.mcmc_load(params, data)
@@ -214,7 +215,7 @@ def _read_bin(path):
 def test_binary_and_thinned_sinks_carry_the_same_samples_as_the_text_dumps(tmp_path):
     """APEMOST_DUMP=binary / thin:N (second half): samples.bin holds the doubles the text
     dumps print; thinning keeps iterations N, 2N, ...; the default text mode is untouched"""
-    n_beta, iters = 6, 6000
+    n_beta, iters = 8, 6000                          # whole rounds: n_swap = 2000 / 8 = 250 divides 6000
     w = wl.simplesin(n_data=128, n_chain=n_beta)
     exe = hostlib.make(str(tmp_path / "sine.exe"), ccflags="-DN_BETA=%d -DBURN_IN_ITERATIONS=600 -DMAX_ITERATIONS=%d" % (n_beta, iters))
     runs = {}

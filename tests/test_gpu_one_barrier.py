@@ -1,0 +1,126 @@
+"""The one-barrier round kernel (apemost_amd/csrc/pt_onebarrier.h: 4 or 8 likelihood waves + owner
++ candidate producer, accept test as a threshold on the data sum, both next proposals prepared
+ahead) against the classic two-phase kernel and against the oracle.  The two kernels make the same
+draws and add the data sum in the same order, so their chains are bit-identical (the accept
+comparison differs in form only: a different decision needs prob_new - prob and ln U to agree to an
+ulp)."""
+import numpy as np
+import pytest
+
+from apemost_amd import capi, workloads as wl
+from apemost_amd.sampler import HipSampler
+from oracle import oracle as orc
+from tests.helpers import assert_match, make_pair, small_workloads, to_oracle
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("params", "params_best", "prob", "prob_best", "prior", "accept", "reject", "swapcount", "ticks", "n_iter",
+          "params_accepts", "params_rejects")
+
+
+def _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=0, pieces=None, **kw):
+    import torch
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=seed, waves_per_chain=waves, flags=flags, **kw)
+    s.set_state(st)
+    d = torch.zeros((n_rounds * n_swap, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
+    done = 0
+    for k in (pieces or (n_rounds,)):
+        s.run_sampler(k, n_swap, d[done * n_swap:].data_ptr())
+        done += k
+    s.synchronize()
+    out = s.get_state(), d.cpu().numpy()
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
+@pytest.mark.parametrize("waves", [4, 8])
+def test_one_barrier_equals_two_phase_kernel_and_oracle(name, waves):
+    w = small_workloads()[name]
+    n_chain, n_rounds, n_swap, seed = 8, 60, 11, 97
+    st, lad, rng = make_pair(w, n_chain, seed=seed)
+    a, sa = _run(w, st, n_chain, n_rounds, n_swap, waves, seed)
+    b, sb = _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=capi.FLAG_TWO_BARRIER_STEP)
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert np.array_equal(sa, sb)
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    assert_match(a, lad, rng, what="one barrier " + name)
+    np.testing.assert_allclose(sa, ref, rtol=1e-9, atol=1e-300)
+    assert a.swapcount.sum() > 0 and 0 < a.accept.sum() < a.n_iter.sum()
+
+
+@pytest.mark.parametrize("n_swap", [1, 2, 15])
+def test_one_barrier_round_shapes(n_swap):
+    """rounds of one step (a barrier at the round start, one per step), of two, of many; launches cut
+    at arbitrary rounds; single-round launches (every swap fused into the next launch's start)"""
+    w = wl.simplesin(n_data=1024, n_chain=16)        # one pass of the data per lane: rows in registers
+    n_chain, n_rounds, seed = 16, 90, 5
+    st, lad, rng = make_pair(w, n_chain, seed=seed)
+    a, sa = _run(w, st, n_chain, n_rounds, n_swap, 8, seed, lds_policy=1)
+    b, sb = _run(w, st, n_chain, n_rounds, n_swap, 8, seed, pieces=(1, 7, 40, 42))
+    c, sc = _run(w, st, n_chain, n_rounds, n_swap, 8, seed, flags=capi.FLAG_SINGLE_ROUND_LAUNCHES)
+    for other, so in ((b, sb), (c, sc)):
+        for f in FIELDS:
+            assert np.array_equal(getattr(a, f), getattr(other, f)), f
+        assert np.array_equal(sa, so)
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True, n_threads=8)
+    assert_match(a, lad, rng, what="round shape %d" % n_swap)
+    np.testing.assert_allclose(sa, ref, rtol=1e-9, atol=1e-300)
+
+
+def test_one_barrier_redraw_path_and_circular_parameters():
+    """step widths of six times the prior box: almost every prepared attempt leaves the box, so the
+    prepared proposals fail and the workgroup takes the redraw path (extra barrier) constantly; with
+    the phase circular (-DCIRCULAR_PARAMS) its first usable attempt wraps instead"""
+    w = small_workloads()["simplesin"]
+    for circular in (0, 1 << 2):
+        st, lad, rng = make_pair(w, 4, seed=3)
+        st.step[:] = (w.pmax - w.pmin) * 6.0
+        lad.step[:] = st.step
+        lad.circular = circular
+        for waves in (4, 8):
+            dev, samples = _run(w, st, 4, 12, 5, waves, 3, circular_params=circular)
+            lad2 = orc.Ladder(w.model, 4, 4, w.data)
+            to_oracle(st, lad2)
+            lad2.circular = circular
+            rng2 = orc.Rng(orc.RNG_STREAMS, 3, lad2)
+            ref = orc.run_sampler(lad2, rng2, 12, 5, record=True)
+            assert_match(dev, lad2, rng2, what="wide steps waves=%d circular=%d" % (waves, circular))
+            np.testing.assert_allclose(samples, ref, rtol=1e-9)
+
+
+def test_one_barrier_maximum_parameter_count():
+    """n_par = 62: one attempt lane per parameter in the owner and the producer; pulse with 30 modes
+    reads its parameters from the chosen LDS row while it evaluates"""
+    rs = np.random.RandomState(9)
+    n_modes = 30
+    nu = np.linspace(10, 12, 300)
+    modes = [(10.03 + 0.065 * k, 0.5 + 0.1 * k) for k in range(n_modes)]
+    y = sum(h / (1 + (2 * np.pi * (f - nu) * 4.0) ** 2) for f, h in modes) + 0.05
+    data = np.stack([nu, y * rs.exponential(1.0, len(nu))], 1)
+
+    class W:
+        pass
+    w = W()
+    w.model, w.n_par, w.data = wl.MODEL_PULSE, 2 + 2 * n_modes, data
+    w.start = np.array([4.0, 0.05] + [v for f, h in modes for v in (f, h)])
+    w.pmin = np.array([0.1, 0] + [v for _ in modes for v in (10, 0)], float)
+    w.pmax = np.array([50, 1] + [v for _ in modes for v in (12, 20)], float)
+    w.step = (w.pmax - w.pmin) * 0.02
+    st, lad, rng = make_pair(w, 3, seed=42)
+    dev, samples = _run(w, st, 3, 6, 4, 4, 42)
+    ref = orc.run_sampler(lad, rng, 6, 4, record=True)
+    assert_match(dev, lad, rng, what="62 parameters")
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+
+
+def test_one_barrier_config2_bench_shape_matches_oracle():
+    """BASELINE config 2 as bench.py runs it: 128 chains x 1024 points, 8 likelihood waves, rows in
+    registers, 32 rounds x 15 steps per launch with the swaps handed over inside the launch"""
+    w = wl.simplesin(n_data=1024, n_chain=128)
+    st, lad, rng = make_pair(w, 128, seed=7)
+    dev, samples = _run(w, st, 128, 64, 15, 0, 7)
+    ref = orc.run_sampler(lad, rng, 64, 15, record=True, n_threads=8)
+    assert_match(dev, lad, rng, what="config 2")
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    assert dev.swapcount.sum() > 5

@@ -115,7 +115,7 @@ def _run_both(w, n_chain, n_rounds, n_swap, waves, seed=42, init_prob=False):
 
 
 @pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4])
 def test_trajectory_matches_oracle(name, waves):
     """every recorded step of every chain: same accept decisions, same swaps, same RNG positions"""
     w = small_workloads()[name]

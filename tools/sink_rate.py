@@ -23,9 +23,10 @@ def main():
     n_beta = 128
     build.build_hip()
     top = tempfile.mkdtemp(dir=scratch, prefix="apemost_sink_")
+    bins = tempfile.mkdtemp(prefix="apemost_sink_bin_")   # executables: /dev/shm is usually mounted noexec
     try:
         w = wl.simplesin(n_data=1024, n_chain=n_beta)
-        exe = hostlib.make(os.path.join(top, "sine.exe"), strict="-std=c99 -O2",
+        exe = hostlib.make(os.path.join(bins, "sine.exe"), strict="-std=c99 -O2",
                            ccflags="-DN_BETA=%d -DBURN_IN_ITERATIONS=2000 -DMAX_ITERATIONS=%d" % (n_beta, iters))
         base = os.path.join(top, "calib")
         os.mkdir(base)
@@ -39,7 +40,7 @@ def main():
             shutil.copytree(base, work)
             exe_n = exe
             if n != iters:
-                exe_n = hostlib.make(os.path.join(top, "sine_short.exe"), strict="-std=c99 -O2",
+                exe_n = hostlib.make(os.path.join(bins, "sine_short.exe"), strict="-std=c99 -O2",
                                      ccflags="-DN_BETA=%d -DMAX_ITERATIONS=%d" % (n_beta, n))
             t0 = time.time()
             subprocess.check_call([exe_n, "run"], cwd=work, env=dict(env, APEMOST_DUMP=mode), stdout=subprocess.DEVNULL)
@@ -50,6 +51,7 @@ def main():
             shutil.rmtree(work)
     finally:
         shutil.rmtree(top, ignore_errors=True)
+        shutil.rmtree(bins, ignore_errors=True)
 
 
 if __name__ == "__main__":
