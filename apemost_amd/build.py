@@ -43,6 +43,12 @@ def build_stamps(verbose=False, wave=0):
     return out
 
 
+def build_dev_stamps(models, waves, verbose=False):
+    """development build of the stamps twin (in-kernel cycle counters)"""
+    return build_dev(models, waves, out=os.path.join(HERE, "libapemost_hip_stamps.so"), extra=["-DAPEMOST_STAMPS"],
+                     verbose=verbose)
+
+
 def build_dev(models, waves, out=None, extra=(), verbose=False):
     """development build: only the given models (ids) and workgroup shapes (wave counts) are
     instantiated, which compiles in seconds instead of minutes.  Never the product library:

@@ -30,6 +30,7 @@ struct RoundArgs {
     unsigned n_rounds; // rounds in this launch; between them the swap attempts are exchanged in-kernel
     u64 round;
     double *samples; // [n_steps][n_chains][n_par+2] or nullptr
+    int tune;        // diagnostic knob of the one-barrier kernel (APEMOST_OB_TUNE), 0 in production
 };
 
 // candidate sets kept in LDS: 8-slot ring with producer waves, WAVES without
@@ -353,18 +354,36 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
 }
 
 // The same rounds with one barrier per step (pt_onebarrier.h): LW likelihood wavefronts plus an
-// owner and a candidate producer.  All-parameter steps only; launches with steps.
+// owner and three candidate producers.  All-parameter steps only; launches with steps.
 //
 // Every role runs its own copy of the round/step loops (the registers a role carries from step to
 // step are then live in its loop only); what the copies share is the barrier sequence: one at the
 // start of a round, one per step, and one more in a step whose prepared proposal has to be redrawn
 // (every wave reads the same LDS flag for that).
+// Diagnostic build (-DAPEMOST_STAMPS): per wave of workgroup 0, the cycles between leaving a step's
+// barrier and arriving at the next one (g_stamps[wave]); g_stamps[15] = whole steps of the owner,
+// barrier to barrier.  Tells which role the others wait for.
+#ifdef APEMOST_STAMPS
+#define OB_STAMP_DECL u64 ob_busy = 0, ob_t0 = 0, ob_total = 0, ob_prev = 0
+#define OB_STAMP_BEGIN ob_t0 = __builtin_amdgcn_s_memtime()
+#define OB_STAMP_END ob_busy += __builtin_amdgcn_s_memtime() - ob_t0
+#define OB_STAMP_FLUSH                                                                            \
+    if (blockIdx.x == 0 && e.lane == 0)                                                           \
+    atomicAdd(&g_stamps[e.hw], ob_busy)
+#else
+#define OB_STAMP_DECL
+#define OB_STAMP_BEGIN
+#define OB_STAMP_END
+#define OB_STAMP_FLUSH
+#endif
+
 template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 2) * kWave) void pt_round_ob_kernel(const RoundArgs a) {
+__global__ __launch_bounds__((LW + 4) * kWave) void pt_round_ob_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA> e;
     const int c = blockIdx.x;
     e.setup_common(a.d, a.sh, c, lds);
+    OB_STAMP_DECL;
     if (e.is_lik()) {
         e.setup_lik(a.d, a.sh, c);
         if (e.hw < 2)
@@ -375,12 +394,13 @@ __global__ __launch_bounds__((LW + 2) * kWave) void pt_round_ob_kernel(const Rou
             __syncthreads();
             for (unsigned s = 0; s < a.n_steps; s++) {
                 const int p = (int)(s & 1);
-                if (e.redraw_pending(p))
-                    __syncthreads();
-                e.lik_step(p);
+                OB_STAMP_BEGIN;
+                e.lik_step(p); // (takes one more barrier inside when a proposal has to be redrawn)
+                OB_STAMP_END;
                 __syncthreads();
             }
         }
+        OB_STAMP_FLUSH;
     } else if (e.is_producer()) {
         e.setup_lanes(a.sh);
         e.producer_prologue();
@@ -388,14 +408,18 @@ __global__ __launch_bounds__((LW + 2) * kWave) void pt_round_ob_kernel(const Rou
         for (unsigned r = 0; r < a.n_rounds; r++) {
             __syncthreads();
             for (unsigned s = 0; s < a.n_steps; s++) {
+                OB_STAMP_BEGIN;
                 if (e.redraw_pending((int)(s & 1)))
                     __syncthreads();
-                e.producer_step(e.tick);
-                e.tick++;
+                e.producer_step();
+                OB_STAMP_END;
                 __syncthreads();
             }
         }
+        OB_STAMP_FLUSH;
     } else {
+        // the others wait for this wave at every barrier and it has little to issue: let it go first
+        __builtin_amdgcn_s_setprio(3);
         e.setup_lanes(a.sh);
         e.setup_owner(a.d, a.sh, c);
         chain_load(e, a.d, a.sh, c, a.cur);
@@ -418,18 +442,27 @@ __global__ __launch_bounds__((LW + 2) * kWave) void pt_round_ob_kernel(const Rou
             __syncthreads();
             for (unsigned s = 0; s < a.n_steps; s++) {
                 const int p = (int)(s & 1);
-                const bool redraw_pending = e.redraw_pending(p);
+                OB_STAMP_BEGIN;
+                // one batch of LDS reads: the redraw flag, what the prepared proposals settled on
+                // for my parameter, and (owner_results) the partial sums
+                const int pending = *e.s_flag(p);
                 if (s > 0) {
+                    e.owner_fetch_selected(p);
                     e.owner_results(p, my_sample);
                     if (my_sample)
                         my_sample += sample_stride;
                 }
+                const bool redraw_pending = __builtin_amdgcn_readfirstlane(pending) != 0;
                 e.owner_choose(p, s == 0);
                 if (redraw_pending) // rare: a proposal in LDS has just been replaced
                     __syncthreads();
                 e.owner_publish(p);
                 e.tick++;
+                OB_STAMP_END;
                 __syncthreads();
+#ifdef APEMOST_STAMPS
+                ob_total += __builtin_amdgcn_s_memtime() - ob_t0;
+#endif
             }
             if (a.n_steps > 0) { // the last step of the round
                 e.owner_results((int)(a.n_steps & 1), my_sample);
@@ -437,6 +470,12 @@ __global__ __launch_bounds__((LW + 2) * kWave) void pt_round_ob_kernel(const Rou
                     my_sample += sample_stride;
             }
         }
+        OB_STAMP_FLUSH;
+#ifdef APEMOST_STAMPS
+        if (blockIdx.x == 0 && e.lane == 0)
+            atomicAdd(&g_stamps[15], ob_total);
+#endif
+        e.owner_settle_counters((u64)a.n_steps * a.n_rounds);
         if (e.lane == 0)
             a.d.n_iter()[c] += (u64)a.n_steps * a.n_rounds;
         wait_for_reader<decltype(e)>(a.d, a.sh, memo, a.cur ^ 1);
@@ -1248,7 +1287,7 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
         break;
     case K_ROUND_OB:
         if constexpr (has_one_barrier(WAVES)) {
-            const dim3 bo((WAVES + 2) * kWave); // + owner + candidate producer
+            const dim3 bo((WAVES + 4) * kWave); // + owner + three candidate producers
             if (coop) {
                 void *params[] = {const_cast<void *>(args)};
                 return hipLaunchCooperativeKernel((const void *)pt_round_ob_kernel<MODEL, WAVES, LDS>, g, bo, params,
@@ -1392,6 +1431,7 @@ extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int
     a.n_rounds = 0;
     a.round = 0;
     a.samples = nullptr;
+    a.tune = 0;
     return launch(s, K_CALC, count, &a, false);
 }
 
@@ -1490,7 +1530,7 @@ struct OccupancyOp {
         if constexpr (has_one_barrier(WAVES)) {
             if (one_barrier)
                 return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS>,
-                                                                    (WAVES + 2) * kWave, lds_bytes);
+                                                                    (WAVES + 4) * kWave, lds_bytes);
         }
         if (kCanProduce && producers)
             return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
@@ -1578,6 +1618,7 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     a.n_rounds = n_rounds;
     a.round = s->round;
     a.samples = d_samples;
+    a.tune = getenv("APEMOST_OB_TUNE") ? atoi(getenv("APEMOST_OB_TUNE")) : 0;
     bool stage = (u64)n_steps * n_rounds >= 4 || s->cfg.lds_policy == 1;
     if (n_rounds > 1) // residency decides when workgroups wait for each other
         stage = s->resident_lds ? stage || !s->resident_plain : false;

@@ -23,11 +23,12 @@
 //     variant of the proposal and goes straight into the next likelihood.  No second barrier, no
 //     hand-over.
 //
-// Roles in a workgroup of LW + 2 wavefronts: waves 0..LW-1 evaluate the likelihood; wave LW (the
+// Roles in a workgroup of LW + 4 wavefronts: waves 0..LW-1 evaluate the likelihood; wave LW (the
 // owner) keeps the chain: counters, current point, best point, sample rows, thresholds and the
-// speculative proposals -- all one step behind the likelihood waves, in their shadow; wave LW+1
-// produces the Gaussian candidates (Philox block, polar test, logarithm, division, square root),
-// one set per step, three ticks in flight.
+// speculative proposals -- all one step behind the likelihood waves, in their shadow; waves
+// LW+1..LW+3 produce the Gaussian candidates, each one set every three steps, one third per step
+// (Philox block + polar test | logarithm | division, square root): a whole set is a ~2300-cycle
+// dependent chain, longer than a step, a third of it is not.
 //
 // Draws, proposals, sums (same tree order as Engine with the same number of likelihood waves) and
 // recorded values are those of Engine; only the form of the accept comparison differs.
@@ -82,9 +83,10 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
 template <int MODEL, int LW, bool LDS_DATA>
 struct ObEngine {
     static constexpr int kLikThreads = LW * kWave;
-    static constexpr int kBlock = (LW + 2) * kWave;
+    static constexpr int kProducers = 3;
+    static constexpr int kBlock = (LW + 1 + kProducers) * kWave;
     static constexpr int kWide = LW < 8 ? 4 : 2;
-    static constexpr bool kShortChain = LW >= 4;
+    static constexpr bool kShortChain = LW >= APEMOST_SHORT_CHAIN_WAVES;
     static constexpr bool kSine = MODEL == APEMOST_MODEL_SIMPLESIN || MODEL == APEMOST_MODEL_SINE3;
 
     // ---- identity ----
@@ -93,7 +95,7 @@ struct ObEngine {
     int tid;       // likelihood thread index (likelihood waves)
     __device__ __forceinline__ bool is_lik() const { return hw < LW; }
     __device__ __forceinline__ bool is_owner() const { return hw == LW; }
-    __device__ __forceinline__ bool is_producer() const { return hw == LW + 1; }
+    __device__ __forceinline__ bool is_producer() const { return hw > LW; }
 
     int n_par, n_data;
     int Q, grp, qidx, n_cand_lanes;
@@ -114,6 +116,7 @@ struct ObEngine {
     double prob, prior, prob_best;
     u64 accept, reject;
     double par_val;     // the step in flight proposes this value for my parameter
+    double sel_a, sel_r; // ... and the next step would, after an accept / after a reject
     double thr;         // S_max of the step in flight
     u64 fail_a, fail_r; // parameter groups whose prepared attempts all failed, per variant
     double cand_y, cand_s, next_y, next_s; // candidates of the tick in flight / of the next one
@@ -192,8 +195,9 @@ struct ObEngine {
         x_abs_max = sh.x_abs_max;
         fail_a = fail_r = 0;
         cand_y = cand_s = next_y = next_s = 0;
-        par_val = thr = 0;
+        par_val = thr = sel_a = sel_r = 0;
         accepted = false;
+        n_accepted = 0;
         m.init_scalar();
         m.set_consts(consts);
         m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
@@ -240,23 +244,39 @@ struct ObEngine {
         s_cand(t)[lane] = cand_end(h, cand_log(h));
     }
 
-    // producer pipeline: set t+2 leaves, set t+3 gets its logarithm, set t+4 its Philox block
-    Half pipe_b, pipe_c;
-    double log_c;
+    // Producer wave j works on the ticks T = t0 + 2 + j (mod 3), one third of the set per step,
+    // timed so that set T is published by the barrier that closes step T - 2 (the owner fetches the
+    // candidates of tick t + 1 while step t is in flight):  step T-4: Philox blocks and polar test,
+    // step T-3: logarithm, step T-2: division, square root, store.
+    Half pipe;
+    double pipe_log;
+    u64 pipe_tick;
+    int pipe_phase; // what the coming step does: 0 blocks, 1 logarithm, 2 finish
     // before the kernel's first barrier (likelihood waves 0 and 1 make the sets of ticks t0 and
-    // t0+1 meanwhile): the pipeline filled for t0+2 and t0+3
+    // t0+1 meanwhile): set t0+2 is two thirds done, set t0+3 one third, set t0+4 not begun
     __device__ __forceinline__ void producer_prologue() {
-        pipe_c = cand_begin(tick + 2);
-        log_c = cand_log(pipe_c);
-        pipe_b = cand_begin(tick + 3);
+        const int j = hw - LW - 1;
+        pipe_tick = tick + 2 + (u64)j;
+        pipe_phase = 2 - j;
+        pipe.y = pipe.v = pipe_log = 0;
+        pipe.ok = false;
+        if (j <= 1)
+            pipe = cand_begin(pipe_tick);
+        if (j == 0)
+            pipe_log = cand_log(pipe);
     }
-    __device__ __forceinline__ void producer_step(u64 t) {
-        const Half a = cand_begin(t + 4);
-        const double lb = cand_log(pipe_b);
-        s_cand(t + 2)[lane] = cand_end(pipe_c, log_c);
-        pipe_c = pipe_b;
-        log_c = lb;
-        pipe_b = a;
+    __device__ __forceinline__ void producer_step() {
+        if (pipe_phase == 0) {
+            pipe = cand_begin(pipe_tick);
+            pipe_phase = 1;
+        } else if (pipe_phase == 1) {
+            pipe_log = cand_log(pipe);
+            pipe_phase = 2;
+        } else {
+            s_cand(pipe_tick)[lane] = cand_end(pipe, pipe_log);
+            pipe_tick += kProducers;
+            pipe_phase = 0;
+        }
     }
 
     // ---- the partial sums of a step, added in Engine's order ----
@@ -319,22 +339,29 @@ struct ObEngine {
         }
         for (; i < n_data; i += kLikThreads)
             acc += m.term(xs[i], ys[i]);
-        return wave_allreduce_sum(acc);
+        return wave_reduce_sum_lane63(acc); // valid in lane 63
     }
 
     // One step of a likelihood wave.  `parity` holds what the previous step published: its partial
     // sums and threshold, and the two prepared proposals of this step.
     __device__ __forceinline__ void lik_step(int parity) {
-        // everything the decision needs is requested at once: the partial sums, the threshold and
-        // BOTH prepared proposals (selecting the row first and reading it afterwards would put a
-        // second LDS round trip on the critical path)
+        // everything the decision needs is requested at once: the partial sums, the threshold, the
+        // redraw flag and BOTH prepared proposals (selecting the row first and reading it afterwards
+        // would put a second LDS round trip on the critical path)
         double part[LW];
         const double *sp = s_part(parity);
 #pragma unroll
         for (int w = 0; w < LW; w++)
             part[w] = sp[w];
         const double limit = *s_thr(parity);
+        const int pending = *s_flag(parity);
         m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
+        if (__builtin_amdgcn_readfirstlane(pending) != 0) {
+            // rare: the owner is replacing a proposal that could not be prepared (redraw path);
+            // every wave of the workgroup takes this barrier, then the rows are read again
+            __syncthreads();
+            m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
+        }
 #pragma unroll
         for (int span = 1; span < LW; span *= 2) {
 #pragma unroll
@@ -343,7 +370,7 @@ struct ObEngine {
         }
         m.pick2(part[0] < limit, n_par);
         const double mine = lik_partial();
-        if (lane == 0)
+        if (lane == 63)
             s_part(parity ^ 1)[hw] = mine;
     }
 
@@ -420,11 +447,21 @@ struct ObEngine {
         if (lane < LW)
             s_part(0)[lane] = 0;
         fail_a = fail_r = 0;
+        sel_a = sel_r = cand() ? row[grp] : 0.0;
     }
 
     // results of the step that just finished (tick - 1 from now on): check_accept through the
     // threshold, counters, mcmc_check_best, the sample row; then the rare redraw of the chosen variant
     bool accepted; // outcome of the step just finished (uniform)
+    unsigned n_accepted; // accepted steps of this launch
+    // accept / reject and the per-parameter counters after n_steps all-parameter steps
+    // (inc_params_accepts / inc_params_rejects bump all of them together, src/mcmc_gettersetter.c:98-109)
+    __device__ __forceinline__ void owner_settle_counters(u64 n_steps) {
+        accept += n_accepted;
+        reject += n_steps - n_accepted;
+        pacc += n_accepted;
+        prej += n_steps - n_accepted;
+    }
     __device__ __forceinline__ void owner_results(int parity, double *sample) {
         const double sum = tree(parity);
         accepted = sum < thr;
@@ -432,10 +469,7 @@ struct ObEngine {
         const double prob_new = m.finish(sum, beta_all, consts, &prior_new);
         if (Model<MODEL>::kHasPrior)
             prior = prior_new; // not restored on reject (quirk Q7)
-        accept += accepted ? 1u : 0u;
-        reject += accepted ? 0u : 1u;
-        pacc += accepted ? 1u : 0u;
-        prej += accepted ? 0u : 1u;
+        n_accepted += accepted ? 1u : 0u; // the four counters move together here (all-parameter steps): settled at the end
         if (accepted) {
             if (cand())
                 cur = par_val;
@@ -463,10 +497,14 @@ struct ObEngine {
     __device__ __forceinline__ void owner_choose(int parity, bool first) {
         double *row = s_prop(parity, (first || accepted) ? 0 : 1);
         const u64 failed = first ? 0 : (accepted ? fail_a : fail_r);
-        if (failed) // (the workgroup takes an extra barrier after this: s_flag(parity) is set)
+        // the value my parameter takes in the chosen proposal was read back when the proposals were
+        // prepared (sel_a / sel_r): no trip to LDS between the accept decision and the next proposals
+        par_val = (first || accepted) ? sel_a : sel_r;
+        if (failed) { // (the workgroup takes an extra barrier after this: s_flag(parity) is set)
             redraw(failed, tick, row);
-        __builtin_amdgcn_wave_barrier();
-        par_val = cand() ? row[grp] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            par_val = cand() ? row[grp] : 0.0;
+        }
         m.load(row, n_par, x_abs_max);
     }
     __device__ __forceinline__ void owner_publish(int parity) {
@@ -475,19 +513,25 @@ struct ObEngine {
         const double2 nx = s_cand(tick + 1)[lane];
         next_y = nx.x;
         next_s = nx.y;
+        // the two proposals of the next step: from the proposal in flight, from the current point
+        fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0));
+        fail_r = attempts(cur, next_y, next_s, s_prop(next, 1));
         // S_max of the step in flight
         double prior_new = 0;
         if (Model<MODEL>::kHasPrior)
             prior_new = m.prior_only(consts);
         const double lu = read_lane(cand_y, 63);
         thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());
-        if (lane == 0)
+        if (lane == 0) {
             *s_thr(next) = thr;
-        // the two proposals of the next step: from the proposal in flight, from the current point
-        fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0));
-        fail_r = attempts(cur, next_y, next_s, s_prop(next, 1));
-        if (lane == 0)
             *s_flag(next) = (fail_a | fail_r) != 0 ? 1 : 0;
+        }
+    }
+    // first thing after the barrier, in one batch with the partial sums: what each prepared proposal
+    // settled on for my parameter
+    __device__ __forceinline__ void owner_fetch_selected(int parity) {
+        sel_a = cand() ? s_prop(parity, 0)[grp] : 0.0;
+        sel_r = cand() ? s_prop(parity, 1)[grp] : 0.0;
     }
 };
 

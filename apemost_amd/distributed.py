@@ -45,17 +45,24 @@ class ShardedLadder:
             return
         dist = self.dist
         with self.e.comm_stream():
+            # RCCL (backend "nccl") is stream-ordered end to end: under comm_stream() the current
+            # stream IS the engine's stream, so the export kernel, the send/recv pair (c10d makes
+            # its communication stream wait for the current one, and wait() makes the current one
+            # wait for the transfer) and the import kernel are chained by events, with no host
+            # synchronisation.  Other backends (gloo in the tests) stage through the host and
+            # need the data complete on both sides of the transfer.
+            ordered = dist.get_backend() == "nccl"
             send = self.e.edge_export(side)
             recv = send.new_empty(send.shape)
-            # Edge exchanges are rare (one pair in n_beta per round), so the two hand-overs between
-            # the engine's stream and the communication backend are plain host synchronisations:
-            # correct for every backend, whatever stream it works on.
-            self.e.fence()
+            if not ordered:
+                self.e.fence()
             ops = [dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)]
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-            self.e.fence()
+            if not ordered:
+                self.e.fence()
             self.e.edge_import(side, recv)
+            self._in_flight = (send, recv)   # keep the buffers alive until the streams are done with them
         self.exchanges += 1
 
     def prime(self):
@@ -74,7 +81,7 @@ class ShardedLadder:
                 for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, peer),
                                                    dist.P2POp(dist.irecv, recv, peer)]):
                     req.wait()
-                self.e.fence()
+                self.e.fence()   # (priming happens once, before anything is timed: plain fences)
 
     def _straddles(self, swap_index):
         a = self.e.swap_pair(swap_index)

@@ -17,15 +17,20 @@ double get_beta(const mcmc *m) { return pt(m)->beta; }
 void inc_swapcount(mcmc *m) { pt(m)->swapcount++; }
 unsigned long get_swapcount(const mcmc *m) { return pt(m)->swapcount; }
 
+/* one block per chain: how often it swapped, where it is, the best point it has seen */
+static void print_point(int chain, const char *label, double prob, const gsl_vector *point) {
+    printf("\tchain %d: %s %f: ", chain, label, prob);
+    dump_vectorln(point);
+}
+
 void print_current_positions(const mcmc **chains, const int n_beta) {
-    int i;
+    int chain;
     printf("printing chain parameters: \n");
-    for (i = 0; i < n_beta; i++) {
-        printf("\tchain %d: swapped %lu times: ", i, get_swapcount(chains[i]));
-        printf("\tchain %d: current %f: ", i, get_prob(chains[i]));
-        dump_vectorln(get_params(chains[i]));
-        printf("\tchain %d: best %f: ", i, get_prob_best(chains[i]));
-        dump_vectorln(get_params_best(chains[i]));
+    for (chain = 0; chain < n_beta; chain++) {
+        const mcmc *m = chains[chain];
+        printf("\tchain %d: swapped %lu times: ", chain, get_swapcount(m));
+        print_point(chain, "current", get_prob(m), get_params(m));
+        print_point(chain, "best", get_prob_best(m), get_params_best(m));
     }
     fflush(stdout);
 }
@@ -60,16 +65,22 @@ double get_chain_beta(unsigned int i, unsigned int n_beta, double beta_0) {
     return BETA_ALIGNMENT(n_beta - i - 1, n_beta, beta_0);
 }
 
-/* beta of the hottest chain such that its predicted step width (step * beta^-1/2 * factor)
- * spans BETA_0_STEPWIDTH of the widest parameter range */
+/* beta of the hottest chain: the one at which the predicted proposal width of the parameter that
+ * fills its range soonest, step * beta^-1/2 * factor, reaches BETA_0_STEPWIDTH times that range:
+ * beta_0 = max_p( BETA_0_STEPWIDTH * (max_p - min_p) / (step_p * factor_p) )^-1/2.  Same operations
+ * on every component as the vector arithmetic of the reference (range scaled, divided by the step,
+ * divided by the factor), without the temporary. */
 double calc_beta_0(mcmc *m, gsl_vector *stepwidth_factors) {
-    gsl_vector *range = dup_vector(get_params_max(m));
-    double widest;
-    gsl_vector_sub(range, get_params_min(m));
-    gsl_vector_scale(range, BETA_0_STEPWIDTH);
-    gsl_vector_div(range, get_steps(m));
-    gsl_vector_div(range, stepwidth_factors);
-    widest = gsl_vector_max(range);
-    gsl_vector_free(range);
+    const unsigned int n = get_n_par(m);
+    double widest = 0;
+    unsigned int p;
+    for (p = 0; p < n; p++) {
+        double reach = get_params_max_for(m, p) - get_params_min_for(m, p);
+        reach = reach * BETA_0_STEPWIDTH;
+        reach = reach / get_steps_for(m, p);
+        reach = reach / gsl_vector_get(stepwidth_factors, p);
+        if (p == 0 || reach > widest)
+            widest = reach;
+    }
     return pow(widest, -0.5);
 }

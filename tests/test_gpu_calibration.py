@@ -180,7 +180,8 @@ def test_config5_shard_size_with_device_calibration():
     for f in ("step", "params", "prob", "params_best", "ticks"):
         assert np.array_equal(getattr(ca, f), getattr(cb, f)) and np.array_equal(getattr(ra, f), getattr(rb, f)), f
     assert np.all(ia >= 200) and set(np.unique(sa)) <= {0, 2}
-    assert np.all(ra.accept + ra.reject == 4) and np.all(ra.n_iter == 4)
+    # (a chain that ran into the iteration limit keeps the counters of its last 200-step block)
+    assert np.all((ra.accept + ra.reject) - (ca.accept + ca.reject) == 4) and np.all(ra.n_iter - ca.n_iter == 4)
     assert np.all(da[..., :7] >= w.pmin) and np.all(da[..., :7] <= w.pmax) and np.all(np.isfinite(da))
     # sub-ladder against the oracle: each chain is independent during calibration
     for c in (0, n_local // 2, n_local - 1):
