@@ -38,8 +38,11 @@ __host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? wav
 // candidate production as a side duty of waves 1-3 (workgroups of at least 4 waves)
 // (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
 __host__ __device__ constexpr bool has_producer(int waves) { return waves >= 4; }
-// the one-barrier round kernel (pt_onebarrier.h) exists for these numbers of likelihood waves
-__host__ __device__ constexpr bool has_one_barrier(int waves) { return waves == 4 || waves == 8; }
+// The one-barrier round kernel (pt_onebarrier.h) is used with 8 likelihood waves per chain (ladders
+// of up to 128 chains).  With 4 (129-512 chains) it was measured 3 % behind the classic kernel on
+// config 4's shard (256 pulse chains x 1024 points: 6.9e7 vs 7.1e7 steps/s): one likelihood wave per
+// SIMD leaves the chain's wave enough issue slots in the classic kernel too.
+__host__ __device__ constexpr bool has_one_barrier(int waves) { return waves == 8; }
 __host__ __device__ constexpr int block_threads(int waves, bool) { return waves * kWave; }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
@@ -978,7 +981,7 @@ static int create_body(apemost_hip_sampler *s) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
         // the round kernel this sampler's stepping launches use: one barrier per step where that
-        // variant exists (4 or 8 likelihood waves per chain), the classic two-phase step otherwise
+        // variant exists (8 likelihood waves per chain), the classic two-phase step otherwise
         s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
         int b_lds = 0, b_plain = 0;
         if (s->lds_data)

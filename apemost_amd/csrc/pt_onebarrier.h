@@ -6,7 +6,7 @@
 // vector (A -> B), then wave 0 alone adds the partial sums, finishes the likelihood, runs the
 // accept test, the bookkeeping and the next proposal, and hands the proposal to the other waves
 // through LDS (B -> A); the second phase is ~1300 of the ~2300 cycles of a step
-// (profiles/r02_c2_stamps.txt).
+// (profiles/r02_c2_stamps_classic.txt).
 //
 // Here the serial phase is taken off the critical path:
 //

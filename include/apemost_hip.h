@@ -84,7 +84,7 @@ enum {
     /* multi-round launches go through hipLaunchCooperativeKernel: the runtime guarantees (or
      * refuses) co-residency of the whole grid instead of the engine's occupancy estimate */
     APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH = 2,
-    /* stepping launches of workgroups with 4 or 8 likelihood waves use the classic two-phase step
+    /* stepping launches of workgroups with 8 likelihood waves use the classic two-phase step
      * (two barriers, the chain's wave alone between them) instead of the one-barrier kernel; same
      * chain either way (A/B comparisons, fallback) */
     APEMOST_HIP_FLAG_TWO_BARRIER_STEP = 4

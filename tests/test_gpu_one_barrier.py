@@ -1,4 +1,4 @@
-"""The one-barrier round kernel (apemost_amd/csrc/pt_onebarrier.h: 4 or 8 likelihood waves + owner
+"""The one-barrier round kernel (apemost_amd/csrc/pt_onebarrier.h: 8 likelihood waves + owner
 + candidate producer, accept test as a threshold on the data sum, both next proposals prepared
 ahead) against the classic two-phase kernel and against the oracle.  The two kernels make the same
 draws and add the data sum in the same order, so their chains are bit-identical (the accept
@@ -33,7 +33,7 @@ def _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=0, pieces=None, **
 
 
 @pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
-@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("waves", [8])
 def test_one_barrier_equals_two_phase_kernel_and_oracle(name, waves):
     w = small_workloads()[name]
     n_chain, n_rounds, n_swap, seed = 8, 60, 11, 97
@@ -78,7 +78,7 @@ def test_one_barrier_redraw_path_and_circular_parameters():
         st.step[:] = (w.pmax - w.pmin) * 6.0
         lad.step[:] = st.step
         lad.circular = circular
-        for waves in (4, 8):
+        for waves in (8,):
             dev, samples = _run(w, st, 4, 12, 5, waves, 3, circular_params=circular)
             lad2 = orc.Ladder(w.model, 4, 4, w.data)
             to_oracle(st, lad2)
@@ -108,7 +108,7 @@ def test_one_barrier_maximum_parameter_count():
     w.pmax = np.array([50, 1] + [v for _ in modes for v in (12, 20)], float)
     w.step = (w.pmax - w.pmin) * 0.02
     st, lad, rng = make_pair(w, 3, seed=42)
-    dev, samples = _run(w, st, 3, 6, 4, 4, 42)
+    dev, samples = _run(w, st, 3, 6, 4, 8, 42)
     ref = orc.run_sampler(lad, rng, 6, 4, record=True)
     assert_match(dev, lad, rng, what="62 parameters")
     np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
