@@ -30,7 +30,6 @@ struct RoundArgs {
     unsigned n_rounds; // rounds in this launch; between them the swap attempts are exchanged in-kernel
     u64 round;
     double *samples; // [n_steps][n_chains][n_par+2] or nullptr
-    int tune;        // diagnostic knob of the one-barrier kernel (APEMOST_OB_TUNE), 0 in production
 };
 
 // candidate sets kept in LDS: 8-slot ring with producer waves, WAVES without
@@ -1434,7 +1433,6 @@ extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int
     a.n_rounds = 0;
     a.round = 0;
     a.samples = nullptr;
-    a.tune = 0;
     return launch(s, K_CALC, count, &a, false);
 }
 
@@ -1621,7 +1619,6 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     a.n_rounds = n_rounds;
     a.round = s->round;
     a.samples = d_samples;
-    a.tune = getenv("APEMOST_OB_TUNE") ? atoi(getenv("APEMOST_OB_TUNE")) : 0;
     bool stage = (u64)n_steps * n_rounds >= 4 || s->cfg.lds_policy == 1;
     if (n_rounds > 1) // residency decides when workgroups wait for each other
         stage = s->resident_lds ? stage || !s->resident_plain : false;
@@ -2000,6 +1997,24 @@ static int rng_device(int device) {
     return APEMOST_HIP_OK;
 }
 
+// device scratch of the two test hooks, released on every path
+struct DeviceScratch {
+    std::vector<void *> blocks;
+    ~DeviceScratch() {
+        for (void *p : blocks)
+            hipFree(p);
+    }
+    template <class T>
+    hipError_t get(T **p, size_t count) {
+        void *q = nullptr;
+        const hipError_t e = hipMalloc(&q, count * sizeof(T));
+        if (e == hipSuccess)
+            blocks.push_back(q);
+        *p = (T *)q;
+        return e;
+    }
+};
+
 extern "C" int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequence, uint64_t offset,
                                    int32_t n, uint32_t *out) {
     int rc = rng_device(device);
@@ -2007,12 +2022,12 @@ extern "C" int apemost_hip_rng_raw(int device, uint64_t seed, uint64_t subsequen
         return rc;
     if (n < 1 || !out)
         return fail(APEMOST_HIP_ERR_INVALID, "rng_raw: bad arguments");
+    DeviceScratch mem;
     unsigned int *d;
-    HIP_TRY(hipMalloc((void **)&d, n * sizeof(unsigned int)));
+    HIP_TRY(mem.get(&d, n));
     hipLaunchKernelGGL(rng_raw_kernel, dim3(1), dim3(kWave), 0, 0, seed, subsequence, offset, n, d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    hipFree(d);
     return APEMOST_HIP_OK;
 }
 
@@ -2024,12 +2039,13 @@ extern "C" int apemost_hip_rng_attempts(int device, uint64_t seed, uint64_t chai
         return rc;
     if (n < 1 || !y || !s || !valid)
         return fail(APEMOST_HIP_ERR_INVALID, "rng_attempts: bad arguments");
+    DeviceScratch mem;
     double *dy, *ds, *dl;
     int *dv;
-    HIP_TRY(hipMalloc((void **)&dy, n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&ds, n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dl, sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dv, n * sizeof(int)));
+    HIP_TRY(mem.get(&dy, n));
+    HIP_TRY(mem.get(&ds, n));
+    HIP_TRY(mem.get(&dl, 1));
+    HIP_TRY(mem.get(&dv, n));
     hipLaunchKernelGGL(rng_attempts_kernel, dim3((n + 63) / 64), dim3(kWave), 0, 0, seed, chain, slot, tick, q0, n,
                        dy, ds, dv, dl);
     HIP_TRY(hipGetLastError());
@@ -2038,10 +2054,6 @@ extern "C" int apemost_hip_rng_attempts(int device, uint64_t seed, uint64_t chai
     HIP_TRY(hipMemcpy(valid, dv, n * sizeof(int), hipMemcpyDeviceToHost));
     if (accept_log_u)
         HIP_TRY(hipMemcpy(accept_log_u, dl, sizeof(double), hipMemcpyDeviceToHost));
-    hipFree(dy);
-    hipFree(ds);
-    hipFree(dl);
-    hipFree(dv);
     return APEMOST_HIP_OK;
 }
 

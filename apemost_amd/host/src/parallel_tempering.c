@@ -193,9 +193,11 @@ static unsigned long gcd_ul(unsigned long a, unsigned long b) {
  *   text     (default) the reference's files: <name>-chain-<i>.prob.dump ("%.15e", chain 0 or
  *            all chains with -DDUMP_ALL_CHAINS; src/mcmc_dump.c:79-88) and prob-chain<i>.dump
  *            ("%6e\t%6e" for every chain; src/parallel_tempering.c:399-401)
- *   binary   one file samples.bin: a 64-byte header, then per kept step n_beta rows of n_par+2
- *            doubles (params..., prob, prob - prior) exactly as the device wrote them
- *            (tools/samples_bin.py reads it and can expand it into the text files)
+ *   binary   one file samples.bin holding what the text files hold, as doubles: a 64-byte header,
+ *            then per kept iteration the parameter vectors of the chains that have parameter dump
+ *            files (chain 0; all chains with -DDUMP_ALL_CHAINS) followed by (prob, prob - prior)
+ *            of every chain (tools/samples_bin.py reads it and expands it into the text files)
+ *   binary:all   the same with the parameter vector of every chain
  *   thin:N   keep every N-th iteration only (either format)
  * The reference prints one line per chain per step, which at device speed is the whole run time
  * (SURVEY 8 f1); binary and thinned sinks are the additive options for that. */
@@ -205,7 +207,10 @@ static unsigned long gcd_ul(unsigned long a, unsigned long b) {
 #endif
 
 typedef struct {
-    int binary;
+    int binary;               /* 0 text, 1 binary, 2 binary with every chain's parameters */
+    unsigned int n_param_chains; /* binary: chains 0..n-1 carry their parameter vectors */
+    double *pack;             /* binary: one batch, packed */
+    size_t pack_capacity;
     unsigned long thin;
     unsigned int n_beta, n_par;
     const char *mode;  /* "w" or "a" */
@@ -219,14 +224,16 @@ static void sink_parse(sample_sink *k) {
     k->binary = 0;
     k->thin = 1;
     while (spec != NULL && *spec != 0) {
-        if (strncmp(spec, "binary", 6) == 0)
+        if (strncmp(spec, "binary:all", 10) == 0)
+            k->binary = 2;
+        else if (strncmp(spec, "binary", 6) == 0)
             k->binary = 1;
         else if (strncmp(spec, "text", 4) == 0)
             k->binary = 0;
         else if (strncmp(spec, "thin:", 5) == 0 && atol(spec + 5) > 0)
             k->thin = (unsigned long)atol(spec + 5);
         else {
-            fprintf(stderr, "APEMOST_DUMP: expected a comma separated list of text, binary, thin:N; got '%s'\n", spec);
+            fprintf(stderr, "APEMOST_DUMP: expected a comma separated list of text, binary, binary:all, thin:N; got '%s'\n", spec);
             exit(1);
         }
         spec = strchr(spec, ',');
@@ -245,7 +252,8 @@ static FILE *open_or_die(const char *name, const char *mode) {
     return f;
 }
 
-static void sink_open(sample_sink *k, unsigned int n_beta, unsigned int n_par, unsigned int n_swap, const char *mode) {
+static void sink_open(sample_sink *k, mcmc **chains, unsigned int n_beta, unsigned int n_par, unsigned int n_swap,
+                      const char *mode) {
     unsigned int i;
     char name[100];
     sink_parse(k);
@@ -255,21 +263,31 @@ static void sink_open(sample_sink *k, unsigned int n_beta, unsigned int n_par, u
     k->bin = NULL;
     k->prob_files = NULL;
     k->batches = 0;
+    k->pack = NULL;
+    k->pack_capacity = 0;
+    k->n_param_chains = 0;
     if (k->binary) {
         unsigned char header[64];
-        uint32_t u32[4];
+        uint32_t u32[4], u32b;
         uint64_t u64v = k->thin;
         const int fresh = mode[0] == 'w' || fopen("samples.bin", "rb") == NULL;
+        /* the chains the text sink would write parameter files for come first in the ladder */
+        while (k->n_param_chains < n_beta && chains[k->n_param_chains]->files != NULL)
+            k->n_param_chains++;
+        if (k->binary == 2)
+            k->n_param_chains = n_beta;
+        u32b = k->n_param_chains;
         k->bin = open_or_die("samples.bin", fresh ? "wb" : "ab");
         if (fresh) {
             memset(header, 0, sizeof header);
             memcpy(header, SINK_MAGIC, 8);
-            u32[0] = 1; /* format version */
+            u32[0] = 2; /* format version */
             u32[1] = n_beta;
             u32[2] = n_par;
             u32[3] = n_swap;
             memcpy(header + 8, u32, sizeof u32);
             memcpy(header + 24, &u64v, sizeof u64v);
+            memcpy(header + 32, &u32b, sizeof u32b);
             fwrite(header, 1, sizeof header, k->bin);
         }
         return;
@@ -294,15 +312,33 @@ static void sink_write(sample_sink *k, mcmc **chains, double *const *h, const un
     unsigned int i, j, p;
     char name[100];
     if (k->binary) {
-        if (k->thin == 1 && n_shards == 1) {
-            fwrite(h[0], sizeof(double), n_steps * k->n_beta * (n_par + 2), k->bin);
-        } else {
-            for (step = skip; step < n_steps; step += k->thin)
-                for (j = 0; j < n_shards; j++) {
-                    const size_t row = (size_t)(lo[j + 1] - lo[j]) * (n_par + 2);
-                    fwrite(h[j] + step * row, sizeof(double), row, k->bin);
-                }
+        /* one record per kept iteration: params of chains 0..n_param_chains-1, then (prob, prob - prior)
+         * of every chain; packed for the whole batch, written with one call */
+        const size_t record = (size_t)k->n_param_chains * n_par + 2 * (size_t)k->n_beta;
+        const size_t kept = skip < n_steps ? (n_steps - skip + k->thin - 1) / k->thin : 0;
+        double *out;
+        if (kept * record > k->pack_capacity) {
+            free(k->pack);
+            k->pack_capacity = kept * record;
+            k->pack = (double *)malloc(k->pack_capacity * sizeof(double));
+            assert(k->pack != NULL);
         }
+        out = k->pack;
+        for (step = skip; step < n_steps; step += k->thin) {
+            double *probs = out + (size_t)k->n_param_chains * n_par;
+            for (j = 0; j < n_shards; j++) {
+                const size_t row = (size_t)(lo[j + 1] - lo[j]) * (n_par + 2);
+                const double *r = h[j] + step * row;
+                for (i = lo[j]; i < lo[j + 1]; i++, r += n_par + 2) {
+                    if (i < k->n_param_chains)
+                        memcpy(out + (size_t)i * n_par, r, n_par * sizeof(double));
+                    probs[2 * i] = r[n_par];
+                    probs[2 * i + 1] = r[n_par + 1];
+                }
+            }
+            out += record;
+        }
+        fwrite(k->pack, sizeof(double), kept * record, k->bin);
         k->batches++;
         return;
     }
@@ -343,6 +379,7 @@ static void sink_flush(sample_sink *k) {
 
 static void sink_close(sample_sink *k) {
     unsigned int i;
+    free(k->pack);
     if (k->bin)
         fclose(k->bin);
     if (k->prob_files) {
@@ -380,7 +417,7 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
         max_rounds = 1;
     if (max_rounds > interval_rounds)
         max_rounds = interval_rounds;
-    sink_open(&sink, n_beta, n_par, n_swap, mode);
+    sink_open(&sink, chains, n_beta, n_par, n_swap, mode);
     acceptance_file = fopen("acceptance_rate.dump.gnuplot", "w");
     if (acceptance_file != NULL) {
         fprintf(acceptance_file, "# format: iteration | number of accepts for each chain\nplot ");

@@ -204,12 +204,10 @@ def test_tempering_interaction_on_host_chains_matches_oracle(tmp_path, monkeypat
 
 
 def _read_bin(path):
-    raw = open(path, "rb").read()
-    assert raw[:8] == b"APEMOSTB"
-    version, n_beta, n_par, n_swap = struct.unpack("<4I", raw[8:24])
-    thin, = struct.unpack("<Q", raw[24:32])
-    rows = np.frombuffer(raw[64:], dtype=np.float64).reshape(-1, n_beta, n_par + 2)
-    return dict(version=version, n_beta=n_beta, n_par=n_par, n_swap=n_swap, thin=thin), rows
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import samples_bin
+    hdr, params, probs = samples_bin.read(path)
+    return hdr, np.array(params), np.array(probs)
 
 
 def test_binary_and_thinned_sinks_carry_the_same_samples_as_the_text_dumps(tmp_path):
@@ -219,7 +217,7 @@ def test_binary_and_thinned_sinks_carry_the_same_samples_as_the_text_dumps(tmp_p
     w = wl.simplesin(n_data=128, n_chain=n_beta)
     exe = hostlib.make(str(tmp_path / "sine.exe"), ccflags="-DN_BETA=%d -DBURN_IN_ITERATIONS=600 -DMAX_ITERATIONS=%d" % (n_beta, iters))
     runs = {}
-    for mode in ("text", "binary", "thin:7", "binary,thin:7"):
+    for mode in ("text", "binary", "thin:7", "binary:all,thin:7"):
         work = tmp_path / mode.replace(":", "_").replace(",", "_")
         _inputs(work, w)
         env = dict(os.environ, APEMOST_SEED="3", APEMOST_DUMP=mode)
@@ -232,18 +230,21 @@ def test_binary_and_thinned_sinks_carry_the_same_samples_as_the_text_dumps(tmp_p
     amp = np.loadtxt(str(t / "amplitude-chain-0.prob.dump"))
     prob2 = np.loadtxt(str(t / "prob-chain2.dump"))
     assert len(amp) == iters and not os.path.exists(str(t / "samples.bin"))
-    hdr, rows = _read_bin(str(runs["binary"] / "samples.bin"))
-    assert hdr == dict(version=1, n_beta=n_beta, n_par=4, n_swap=2000 // n_beta, thin=1) and rows.shape == (iters, n_beta, 6)
-    assert np.array_equal(_rt(rows[:, 0, 0]), amp)
-    np.testing.assert_allclose(rows[:, 2, 4:6], prob2, rtol=2e-6)
+    hdr, params, probs = _read_bin(str(runs["binary"] / "samples.bin"))
+    assert hdr == dict(version=2, n_beta=n_beta, n_par=4, n_swap=2000 // n_beta, thin=1, n_param_chains=1)
+    assert params.shape == (iters, 1, 4) and probs.shape == (iters, n_beta, 2)
+    assert np.array_equal(_rt(params[:, 0, 0]), amp)
+    np.testing.assert_allclose(probs[:, 2], prob2, rtol=2e-6)
     assert not os.path.exists(str(runs["binary"] / "prob-chain0.dump"))
     for f in ("acceptance_rate.dump", "calibration_results"):
         assert (runs["binary"] / f).read_text() == (t / f).read_text()
     thin_amp = np.loadtxt(str(runs["thin:7"] / "amplitude-chain-0.prob.dump"))
     assert np.array_equal(thin_amp, amp[6::7])                      # iterations 7, 14, ...
     assert np.array_equal(np.loadtxt(str(runs["thin:7"] / "prob-chain2.dump")), prob2[6::7])
-    hdr7, rows7 = _read_bin(str(runs["binary,thin:7"] / "samples.bin"))
-    assert hdr7["thin"] == 7 and np.array_equal(rows7, rows[6::7])
+    hdr7, params7, probs7 = _read_bin(str(runs["binary:all,thin:7"] / "samples.bin"))
+    assert hdr7["thin"] == 7 and hdr7["n_param_chains"] == n_beta
+    assert np.array_equal(params7[:, 0], params[6::7, 0]) and np.array_equal(probs7, probs[6::7])
+    assert params7.shape == (len(amp[6::7]), n_beta, 4)
     # tools/samples_bin.py expands the binary file into the reference's text files
     out = tmp_path / "expanded"
     out.mkdir()

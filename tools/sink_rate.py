@@ -35,7 +35,7 @@ def main():
         env = dict(os.environ, APEMOST_SEED="1")
         for phase in ("calibrate_first", "calibrate_rest"):
             subprocess.check_call([exe, phase], cwd=base, env=env, stdout=subprocess.DEVNULL)
-        for mode, n in (("binary", iters), ("binary,thin:10", iters), ("text,thin:100", iters), ("text", iters // 30)):
+        for mode, n in (("binary", iters), ("binary:all", iters), ("binary,thin:10", iters), ("text,thin:100", iters), ("text", iters // 30)):
             work = os.path.join(top, mode.replace(",", "_").replace(":", ""))
             shutil.copytree(base, work)
             exe_n = exe

@@ -27,7 +27,7 @@ def dominant(rows):
     tot = {}
     for r in rows:
         k = r["Kernel_Name"]
-        if "pt_round_kernel" in k:
+        if "pt_round" in k:
             tot[k] = tot.get(k, 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return max(tot, key=tot.get) if tot else None
 
