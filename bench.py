@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the device calibration before the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even with one rank")
     a = ap.parse_args()
     for k, v in CONFIGS[a.config].items():
         if getattr(a, k, None) is None:
@@ -117,9 +118,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n_local = a.chains_per_gpu
     n_global = n_local * world
@@ -153,7 +156,7 @@ def main():
     if not a.no_samples:
         samples = torch.zeros((R, n_swap, n_local, w.n_par + 2), dtype=torch.float64, device="cuda")
     eng = HipShardEngine(s, torch)
-    ladder = ShardedLadder(eng, n_global, lo, n_local, rank, world, dist if world > 1 else None)
+    ladder = ShardedLadder(eng, n_global, lo, n_local, rank, world, dist if use_dist else None)
 
     ladder.prime()
 
@@ -164,7 +167,7 @@ def main():
     def sync_all():
         s.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -181,7 +184,7 @@ def main():
     capi.check(s.L.apemost_hip_timer_end(s._h, C.byref(ev_ms), C.byref(launches)))
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -242,7 +245,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     s.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
