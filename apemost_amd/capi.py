@@ -11,8 +11,10 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH, FLAG_TWO_BARRIER_STEP = 1, 2, 4
+# the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP, -DADAPT)
+FLAG_PROPOSAL_LOGISTIC, FLAG_PROPOSAL_UNIFORM, FLAG_RANDOMSWAP, FLAG_ADAPT = 8, 16, 32, 64
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_CALIBRATION = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -31,7 +33,7 @@ class Config(C.Structure):
                 ("n_cols", C.c_int32), ("waves_per_chain", C.c_int32), ("lds_policy", C.c_int32),
                 ("flags", C.c_int32), ("chain_offset", C.c_int64),
                 ("n_chains_global", C.c_int64), ("seed", C.c_uint64), ("sigma", C.c_double),
-                ("hmin", C.c_double), ("circular_params", C.c_uint64)]
+                ("hmin", C.c_double), ("circular_params", C.c_uint64), ("adapt_target", C.c_double)]
 
 
 class StateView(C.Structure):
@@ -58,6 +60,7 @@ EXPORTS = [
     "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
     "apemost_hip_samples_read", "apemost_hip_samples_free", "apemost_hip_samples_read_async",
     "apemost_hip_samples_wait", "apemost_hip_host_alloc", "apemost_hip_host_free", "apemost_hip_swap_pair",
+    "apemost_hip_sampler_swap_pair",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_edge_exchange", "apemost_hip_run_shards",
     "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_calibrate_begin",
@@ -119,6 +122,8 @@ def lib():
     L.apemost_hip_host_free.argtypes = [vp]
     L.apemost_hip_swap_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]
     L.apemost_hip_swap_pair.restype = C.c_int64
+    L.apemost_hip_sampler_swap_pair.argtypes = [C.c_void_p, C.c_uint64]
+    L.apemost_hip_sampler_swap_pair.restype = C.c_int64
     L.apemost_hip_edge_doubles.argtypes = [C.c_int32]
     L.apemost_hip_edge_doubles.restype = C.c_int32
     L.apemost_hip_edge_export.argtypes = [vp, C.c_int, vp]

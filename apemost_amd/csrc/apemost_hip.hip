@@ -187,16 +187,33 @@ struct SwapMemo { // two named slots, not arrays: a run-time subscript would put
 // agree without negotiating.  Records are read from half `half` of the state block; `shared`
 // selects agent-scope loads (records published inside this launch) over plain ones (records
 // stored by the previous launch).  Returns the partner's local chain index, or -1.
+// the draws of swap attempt `swap_index`: the lower chain of the pair (-1: no attempt) and the
+// uniform of the acceptance test.  Default: parallel_tempering_decide_swap_now (:87-97), words 0
+// and 1.  -DRANDOMSWAP: parallel_tempering_decide_swap_random(chains, n_beta, 1) (:47-64) draws
+// swap_probability first and compares it with 1.0 / n_swap for the n_swap = 1 its caller passes.
+template <bool VARIANTS>
+__device__ __forceinline__ long long swap_draws(const ChainShape &sh, u64 swap_index, double &u_accept) {
+    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, swap_index);
+    const int nb = (int)sh.n_global;
+    double u = u32_to_uniform(b.x);
+    u_accept = u32_to_uniform(b.y);
+    if (VARIANTS && (sh.variant & kVariantRandomSwap)) {
+        if (!(u < 1.0 / 1))
+            return -1;
+        u = u32_to_uniform(b.y);
+        u_accept = u32_to_uniform(b.z);
+    }
+    return (int)(nb * 1000 * u) % (nb - 1);
+}
+
 template <class E>
 __device__ __forceinline__ int swap_apply(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
                                           u64 swap_index, bool shared) {
-    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, swap_index);
-    const double u = u32_to_uniform(b.x);
-    const double lc = log(u32_to_uniform(b.y));
-    const int nb = (int)sh.n_global;
-    const long long a = (int)(nb * 1000 * u) % (nb - 1);
+    double u_accept;
+    const long long a = swap_draws<E::kVariants>(sh, swap_index, u_accept);
+    const double lc = log(u_accept);
     const long long g = sh.chain_offset + c;
-    if (g != a && g != a + 1)
+    if (a < 0 || (g != a && g != a + 1))
         return -1;
     const int n = sh.n_par;
     const int row = c + 1;
@@ -262,11 +279,10 @@ __device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const C
                                                u64 swap_index, SwapMemo &memo) {
     if (sh.n_global <= 1 || e.wave != 0)
         return;
-    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, swap_index);
-    const int nb = (int)sh.n_global;
-    const long long a = (int)(nb * 1000 * u32_to_uniform(b.x)) % (nb - 1);
+    double u_accept;
+    const long long a = swap_draws<E::kVariants>(sh, swap_index, u_accept);
     const long long g = sh.chain_offset + c;
-    if (g != a && g != a + 1)
+    if (a < 0 || (g != a && g != a + 1))
         return;
     const int partner = (g == a) ? c + 1 : c - 1;
     if (partner < 0 || partner >= sh.n_chains) {
@@ -739,6 +755,41 @@ __global__ void rng_attempts_kernel(u64 seed, u64 chain, int slot, u64 tick, u64
 }
 
 // edge records for sharded ladders: beta, prob, prob_best, params[n], params_best[n]
+// adapt() of -DADAPT (src/parallel_tempering.c:282-301), called by the reference once per round
+// between the n_swap steps and tempering_interaction (:404): one thread per chain.  The counters
+// summed over the parameters (src/mcmc_gettersetter.c:25-41), accepts / REJECTS against the
+// target, all step widths of the chain scaled by 0.99 or by the double 1 / 0.99
+// (gsl_vector_scale), counters restarted past 100000 counted updates (reset_accept_rejects).
+// A kernel of its own rather than a tail of the round kernels: those carry no register for it.
+__global__ void pt_adapt_kernel(DevArrays d, double target) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n)
+        return;
+    const int n = d.np;
+    u64 *pacc = d.params_accepts() + (size_t)c * n, *prej = d.params_rejects() + (size_t)c * n;
+    double *step = d.step() + (size_t)c * n;
+    u64 acc = 0, rej = 0;
+    for (int p = 0; p < n; p++) {
+        acc += pacc[p];
+        rej += prej[p];
+    }
+    if (acc + rej < 20000)
+        return;
+    const double ratio = (double)acc * 1.0 / (double)rej;
+    if (ratio < target - 0.05) {
+        for (int p = 0; p < n; p++)
+            step[p] *= 0.99;
+    } else if (ratio > target + 0.05) {
+        for (int p = 0; p < n; p++)
+            step[p] *= 1 / 0.99;
+    }
+    if (acc + rej > 100000) {
+        for (int p = 0; p < n; p++)
+            pacc[p] = prej[p] = 0;
+        d.accept()[c] = d.reject()[c] = 0;
+    }
+}
+
 __global__ void edge_export_kernel(DevArrays d, int n_par, int cur, int row, double *buf) {
     const int t = threadIdx.x;
     if (t == 0) {
@@ -816,6 +867,8 @@ struct apemost_hip_sampler {
     hipEvent_t ev_copy;
     u64 *h_word;             // pinned copy of the launch error word, refreshed by every async read
     bool one_barrier;    // stepping launches use pt_round_ob_kernel
+    int kmodel;          // template argument of this sampler's kernels: cfg.model, + kVariantModel when a
+                         // non-default proposal law or swap schedule is asked for (pt_device.h)
     bool cooperative;    // multi-round launches through hipLaunchCooperativeKernel
     bool handoff_failed; // an in-launch hand-off timed out once: single-round launches from then on
 };
@@ -969,6 +1022,15 @@ static int create_body(apemost_hip_sampler *s) {
     s->sh.consts.sigma = cfg->sigma;
     s->sh.consts.hmin = cfg->hmin;
     s->sh.circular = cfg->circular_params;
+    if (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC)
+        s->sh.circular |= (u64)kProposalLogistic << kProposalShift;
+    if (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM)
+        s->sh.circular |= (u64)kProposalFlat << kProposalShift;
+    s->sh.variant = (cfg->flags & APEMOST_HIP_FLAG_RANDOMSWAP) ? kVariantRandomSwap : 0;
+    s->kmodel = cfg->model + ((cfg->flags & (APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC | APEMOST_HIP_FLAG_PROPOSAL_UNIFORM |
+                                             APEMOST_HIP_FLAG_RANDOMSWAP))
+                                  ? kVariantModel
+                                  : 0);
     s->sh.x_abs_max = INFINITY; // until set_data
     HIP_TRY(hipStreamSynchronize(s->stream));
     if ((rc = enable_big_lds(s)))
@@ -984,9 +1046,9 @@ static int create_body(apemost_hip_sampler *s) {
         s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
         int b_lds = 0, b_plain = 0;
         if (s->lds_data)
-            HIP_TRY(round_occupancy<true>(cfg->model, s->waves, s->producers, s->one_barrier,
+            HIP_TRY(round_occupancy<true>(s->kmodel, s->waves, s->producers, s->one_barrier,
                                           s->one_barrier ? ob_lds_bytes(s, true) : s->lds_bytes, &b_lds));
-        HIP_TRY(round_occupancy<false>(cfg->model, s->waves, s->producers, s->one_barrier,
+        HIP_TRY(round_occupancy<false>(s->kmodel, s->waves, s->producers, s->one_barrier,
                                        s->one_barrier ? ob_lds_bytes(s, false) : s->lds_fixed_bytes, &b_plain));
         const long long cus = prop.multiProcessorCount;
         s->resident_lds = s->lds_data && (long long)cfg->n_chains <= (long long)(b_lds - 1) * cus;
@@ -997,7 +1059,9 @@ static int create_body(apemost_hip_sampler *s) {
         }
         s->resident_ok = s->resident_lds || s->resident_plain;
         s->cooperative = (cfg->flags & APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH) && prop.cooperativeLaunch;
-        if (cfg->flags & APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES)
+        // -DADAPT: adapt() sits between a round's steps and its swap attempt and runs as a launch
+        // of its own (pt_adapt_kernel), so every round is a launch
+        if (cfg->flags & (APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_ADAPT))
             s->resident_ok = false;
     }
     return APEMOST_HIP_OK;
@@ -1022,8 +1086,13 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     if (cfg->n_par < 64 && (cfg->circular_params >> cfg->n_par) != 0)
         return fail(APEMOST_HIP_ERR_INVALID, "circular_params names a parameter beyond n_par");
     if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH |
-                       APEMOST_HIP_FLAG_TWO_BARRIER_STEP))
+                       APEMOST_HIP_FLAG_TWO_BARRIER_STEP | APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC |
+                       APEMOST_HIP_FLAG_PROPOSAL_UNIFORM | APEMOST_HIP_FLAG_RANDOMSWAP | APEMOST_HIP_FLAG_ADAPT))
         return fail(APEMOST_HIP_ERR_INVALID, "unknown bits in flags: 0x%x", (unsigned)cfg->flags);
+    if ((cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC) && (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM))
+        return fail(APEMOST_HIP_ERR_INVALID, "PROPOSAL_LOGISTIC and PROPOSAL_UNIFORM are alternatives");
+    if (!(cfg->adapt_target >= 0 && cfg->adapt_target < 1e300))
+        return fail(APEMOST_HIP_ERR_INVALID, "adapt_target %g invalid", cfg->adapt_target);
     if (cfg->n_chains_global > 2000000)
         return fail(APEMOST_HIP_ERR_INVALID, "n_beta*1000 must fit an int (interaction.c:92)");
     switch (cfg->model) {
@@ -1071,6 +1140,11 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->h_word = nullptr;
     s->handoff_failed = false;
     s->waves = choose_waves(*cfg);
+    if (s->waves == 6 && (cfg->flags & (APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC | APEMOST_HIP_FLAG_PROPOSAL_UNIFORM |
+                                        APEMOST_HIP_FLAG_RANDOMSWAP))) {
+        delete s;
+        return fail(APEMOST_HIP_ERR_INVALID, "the proposal / swap variants are built for 1, 2, 4 or 8 waves per chain");
+    }
     rc = create_body(s);
     if (rc != APEMOST_HIP_OK) {
         release(s); // the stream, the events and every allocation made so far
@@ -1301,11 +1375,11 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
         }
         break;
     case K_CALC:
-        hipLaunchKernelGGL((pt_calc_model_kernel<MODEL, WAVES, LDS>), g, b, lds, st,
+        hipLaunchKernelGGL((pt_calc_model_kernel<MODEL % kVariantModel, WAVES, LDS>), g, b, lds, st,
                            *(const RoundArgs *)args);
         break;
     case K_EVAL:
-        hipLaunchKernelGGL((pt_loglike_kernel<MODEL, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
+        hipLaunchKernelGGL((pt_loglike_kernel<MODEL % kVariantModel, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
         break;
     case K_CALIB:
         if (kCanProduce && producers)
@@ -1329,8 +1403,14 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
 #ifndef APEMOST_DEV_WAVES
 #define APEMOST_DEV_WAVES 0x156 // 1, 2, 4, 6, 8
 #endif
+// the variant instantiations (MODEL + kVariantModel: non-default proposal law / swap schedule) exist
+// for the workgroup shapes the engine chooses by itself: 1, 2, 4, 8 waves (build time)
+#ifndef APEMOST_DEV_VARIANTS
+#define APEMOST_DEV_VARIANTS 0x116
+#endif
 constexpr bool built(int model, int waves) {
-    return ((APEMOST_DEV_MODELS >> model) & 1) && ((APEMOST_DEV_WAVES >> waves) & 1);
+    return ((APEMOST_DEV_MODELS >> (model % kVariantModel)) & 1) && ((APEMOST_DEV_WAVES >> waves) & 1) &&
+           (model < kVariantModel || ((APEMOST_DEV_VARIANTS >> waves) & 1));
 }
 
 // f.template run<MODEL, WAVES>() for the sampler's model and workgroup shape
@@ -1372,6 +1452,14 @@ static hipError_t dispatch(int model, int waves, const F &f) {
         return dispatch_w<APEMOST_MODEL_PULSE_VROT>(waves, f);
     case APEMOST_MODEL_SINE3:
         return dispatch_w<APEMOST_MODEL_SINE3>(waves, f);
+    case kVariantModel + APEMOST_MODEL_SIMPLESIN:
+        return dispatch_w<kVariantModel + APEMOST_MODEL_SIMPLESIN>(waves, f);
+    case kVariantModel + APEMOST_MODEL_PULSE:
+        return dispatch_w<kVariantModel + APEMOST_MODEL_PULSE>(waves, f);
+    case kVariantModel + APEMOST_MODEL_PULSE_VROT:
+        return dispatch_w<kVariantModel + APEMOST_MODEL_PULSE_VROT>(waves, f);
+    case kVariantModel + APEMOST_MODEL_SINE3:
+        return dispatch_w<kVariantModel + APEMOST_MODEL_SINE3>(waves, f);
     }
     return hipErrorInvalidDeviceFunction;
 }
@@ -1407,7 +1495,7 @@ static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void 
     op.lds = kind == K_ROUND_OB ? ob_lds_bytes(s, op.lds_data) : op.lds_data ? s->lds_bytes : s->lds_fixed_bytes;
     op.st = s->stream;
     op.args = args;
-    const hipError_t err = dispatch(s->cfg.model, s->waves, op);
+    const hipError_t err = dispatch(s->kmodel, s->waves, op);
     if (err != hipSuccess)
         return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));
     return APEMOST_HIP_OK;
@@ -1492,11 +1580,11 @@ static hipError_t set_lds_attr(size_t bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
         return e;
-    e = hipFuncSetAttribute((const void *)pt_calc_model_kernel<MODEL, WAVES, true>,
+    e = hipFuncSetAttribute((const void *)pt_calc_model_kernel<MODEL % kVariantModel, WAVES, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
         return e;
-    e = hipFuncSetAttribute((const void *)pt_loglike_kernel<MODEL, WAVES, true>,
+    e = hipFuncSetAttribute((const void *)pt_loglike_kernel<MODEL % kVariantModel, WAVES, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
         return e;
@@ -1556,7 +1644,7 @@ static int enable_big_lds(apemost_hip_sampler *s) {
         return APEMOST_HIP_OK;
     LdsAttrOp op;
     op.bytes = s->lds_bytes;
-    const hipError_t e = dispatch(s->cfg.model, s->waves, op);
+    const hipError_t e = dispatch(s->kmodel, s->waves, op);
     if (e != hipSuccess)
         return fail(APEMOST_HIP_ERR_RUNTIME, "hipFuncSetAttribute(LDS %zu B): %s", s->lds_bytes,
                     hipGetErrorString(e));
@@ -1632,6 +1720,12 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     }
     if (rc)
         return rc;
+    if ((s->cfg.flags & APEMOST_HIP_FLAG_ADAPT) && n_steps > 0 && which < 0) {
+        // a round of run_sampler has stepped: adapt() before its swap attempt (n_rounds is 1 here)
+        const double target = s->cfg.adapt_target != 0 ? s->cfg.adapt_target : 0.5;
+        hipLaunchKernelGGL(pt_adapt_kernel, dim3((s->cfg.n_chains + 255) / 256), dim3(256), 0, s->stream, s->d, target);
+        HIP_TRY(hipGetLastError());
+    }
     s->cur ^= 1;
     s->launches++;
     s->round += (apply_swap ? 1 : 0) + (n_rounds - 1); // swap attempts consumed by this launch
@@ -1769,6 +1863,21 @@ extern "C" int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t 
     return (int)(nb * 1000 * u) % (nb - 1);
 }
 
+extern "C" int64_t apemost_hip_sampler_swap_pair(const apemost_hip_sampler *s, uint64_t round) {
+    if (!s || s->cfg.n_chains_global <= 1)
+        return -1;
+    if (!(s->cfg.flags & APEMOST_HIP_FLAG_RANDOMSWAP))
+        return apemost_hip_swap_pair(s->cfg.seed, round, s->cfg.n_chains_global);
+    const uint64_t sub = APEMOST_HIP_SWAP_SUBSEQUENCE;
+    uint32_t ctr[4] = {(uint32_t)round, (uint32_t)(round >> 32), (uint32_t)sub, (uint32_t)(sub >> 32)};
+    uint32_t key[2] = {(uint32_t)s->cfg.seed, (uint32_t)(s->cfg.seed >> 32)}, out[4];
+    philox_host(ctr, key, out);
+    if (!(out[0] * (1.0 / 4294967296.0) < 1.0 / 1)) // swap_probability < 1.0 / n_swap, n_swap = 1
+        return -1;
+    const int nb = (int)s->cfg.n_chains_global;
+    return (int)(nb * 1000 * (out[1] * (1.0 / 4294967296.0))) % (nb - 1);
+}
+
 extern "C" int32_t apemost_hip_edge_doubles(int32_t n_par) { return 3 + 2 * n_par; }
 
 extern "C" int apemost_hip_edge_export(apemost_hip_sampler *s, int side, double *d_buf) {
@@ -1846,7 +1955,7 @@ extern "C" int apemost_hip_edge_exchange(apemost_hip_sampler *lower, apemost_hip
 
 // the shard pair (j, j+1) the swap attempt `index` straddles, or -1
 static int straddled_edge(apemost_hip_sampler **sh, int n_shards, u64 index) {
-    const int64_t a = apemost_hip_swap_pair(sh[0]->cfg.seed, index, sh[0]->cfg.n_chains_global);
+    const int64_t a = apemost_hip_sampler_swap_pair(sh[0], index);
     for (int j = 0; a >= 0 && j + 1 < n_shards; j++)
         if (a == sh[j]->cfg.chain_offset + sh[j]->cfg.n_chains - 1)
             return j;

@@ -87,7 +87,9 @@ struct ObEngine {
     static constexpr int kBlock = (LW + 1 + kProducers) * kWave;
     static constexpr int kWide = LW < 8 ? 4 : 2;
     static constexpr bool kShortChain = LW >= APEMOST_SHORT_CHAIN_WAVES;
-    static constexpr bool kSine = MODEL == APEMOST_MODEL_SIMPLESIN || MODEL == APEMOST_MODEL_SINE3;
+    static constexpr bool kVariants = MODEL >= kVariantModel; // see kVariantModel (pt_device.h)
+    static constexpr int kBase = MODEL % kVariantModel;
+    static constexpr bool kSine = kBase == APEMOST_MODEL_SIMPLESIN || kBase == APEMOST_MODEL_SINE3;
 
     // ---- identity ----
     int lane, hw;  // lane, hardware wave index in the workgroup
@@ -107,8 +109,8 @@ struct ObEngine {
     double *lds;
     u64 tick; // tick of the step in flight (uniform in the workgroup)
     double beta_all, x_abs_max;
-    Model<MODEL> m;
-    ObThreshold<MODEL> thr_fn;
+    Model<kBase> m;
+    ObThreshold<kBase> thr_fn;
 
     // ---- owner: the chain (same meaning as Engine's fields) ----
     double cur, best, stepw, lo, hi;
@@ -218,6 +220,13 @@ struct ObEngine {
             h.y = -1 + 2 * u32_to_uniform(b.y);
             h.v = x * x + h.y * h.y;
             h.ok = b.x != 0 && b.y != 0 && !(h.v > 1.0 || h.v == 0);
+            if (kVariants && proposal_law(circular) != kProposalGaussian) { // uniform; see Engine::cand_begin
+                const double x0 = u32_to_uniform(b.x);
+                const bool logistic = proposal_law(circular) == kProposalLogistic;
+                h.y = x0;
+                h.v = logistic ? x0 / (1 - x0) : 1.0;
+                h.ok = logistic ? b.x != 0 : true;
+            }
         } else if (lane == 63) {
             const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)n_par, t << kTickShift);
             h.v = u32_to_uniform(b.x);
@@ -234,6 +243,11 @@ struct ObEngine {
             const double sq = sqrt(-2.0 * lg / h.v);
             c.x = h.y;
             c.y = h.ok ? sq : __builtin_nan("");
+            if (kVariants && proposal_law(circular) != kProposalGaussian) { // uniform; see Engine::cand_pair
+                if (proposal_law(circular) == kProposalLogistic)
+                    c.x = lg;
+                c.y = h.ok ? 1.0 : __builtin_nan("");
+            }
         } else if (lane == 63) {
             c.x = lg;
         }
@@ -380,7 +394,11 @@ struct ObEngine {
     __device__ __forceinline__ u64 attempts(double from, double cy, double cs, double *row) const {
         double prop = from + stepw * cy * cs;
         bool inside = !(prop > hi || prop < lo);
-        if (circular != 0) {
+        if (circular != 0) { // uniform: a non-default proposal law, or some parameter is circular
+            if (kVariants && proposal_law(circular) == kProposalFlat) {
+                prop = from + flat_jump(stepw, cy);
+                inside = !(prop > hi || prop < lo);
+            }
             const bool wrap = !inside && ((circular >> grp) & 1);
             if (wrap)
                 prop = wrap_circular(prop, lo, hi);
@@ -409,9 +427,11 @@ struct ObEngine {
                     }
                     break;
                 }
-                double y, s;
-                const bool v = gaussian_attempt(seed, g, p, t, (u64)(qbase + (unsigned)lane), y, s);
-                double pr = c0 + w0 * y * s;
+                double jump;
+                const bool v = jump_attempt(kVariants ? proposal_law(circular) : kProposalGaussian, seed, g, p, t,
+                                            (u64)(qbase + (unsigned)lane),
+                                            w0, jump);
+                double pr = c0 + jump;
                 bool inside = !(pr > hi0 || pr < lo0);
                 if (!inside && ((circular >> p) & 1)) {
                     pr = wrap_circular(pr, lo0, hi0);
@@ -467,7 +487,7 @@ struct ObEngine {
         accepted = sum < thr;
         double prior_new = prior;
         const double prob_new = m.finish(sum, beta_all, consts, &prior_new);
-        if (Model<MODEL>::kHasPrior)
+        if (Model<kBase>::kHasPrior)
             prior = prior_new; // not restored on reject (quirk Q7)
         n_accepted += accepted ? 1u : 0u; // the four counters move together here (all-parameter steps): settled at the end
         if (accepted) {
@@ -518,7 +538,7 @@ struct ObEngine {
         fail_r = attempts(cur, next_y, next_s, s_prop(next, 1));
         // S_max of the step in flight
         double prior_new = 0;
-        if (Model<MODEL>::kHasPrior)
+        if (Model<kBase>::kHasPrior)
             prior_new = m.prior_only(consts);
         const double lu = read_lane(cand_y, 63);
         thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());

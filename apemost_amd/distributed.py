@@ -199,8 +199,7 @@ class HipShardEngine:
         self._ext = torch.cuda.ExternalStream(sampler.stream)
 
     def swap_pair(self, round_):
-        from . import capi
-        return capi.swap_pair(self.s.seed, round_, self.s.n_chains_global)
+        return self.s.swap_pair(round_)
 
     def comm_stream(self):
         # enqueue the NCCL(=RCCL) ops relative to the engine's own stream: no host sync needed

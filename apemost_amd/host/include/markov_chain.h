@@ -17,19 +17,16 @@
 #define CIRCULAR_PARAMS 0
 #endif
 
-/* Compile-time variants of the reference that the device engine does not implement: refuse to
- * build rather than silently sample something else. */
-#ifdef PROPOSAL_LOGISTIC
-#error "PROPOSAL_LOGISTIC: the MI355X engine implements the default Gaussian proposal only"
+/* Compile-time variants of the reference.  -DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM
+ * (src/mcmc_gettersetter.c:290-305), -DRANDOMSWAP (src/parallel_tempering_interaction.c:130-131)
+ * and -DADAPT (src/parallel_tempering.c:282-301) are carried to the device engine as
+ * apemost_hip_config.flags (src/apemost_bridge.c).  What the engine does not implement refuses
+ * to build rather than silently sample something else. */
+#if defined(PROPOSAL_LOGISTIC) && defined(PROPOSAL_UNIFORM)
+#error "PROPOSAL_LOGISTIC and PROPOSAL_UNIFORM are alternatives"
 #endif
-#ifdef PROPOSAL_UNIFORM
-#error "PROPOSAL_UNIFORM: the MI355X engine implements the default Gaussian proposal only"
-#endif
-#ifdef RANDOMSWAP
-#error "RANDOMSWAP: the MI355X engine implements the default swap schedule (decide_swap_now) only"
-#endif
-#if defined(RWM) || defined(ADAPT)
-#error "RWM / ADAPT: adaptive step widths during the run are not implemented by the MI355X engine"
+#ifdef RWM
+#error "RWM: per-step adaptive step widths are not implemented by the MI355X engine (nor compilable in the reference)"
 #endif
 #if defined(CALIBRATE_MULTILIN) || defined(CALIBRATE_QUADRATIC) || defined(CALIBRATE_ALTERNATE)
 #error "alternate calibrators are not implemented by the MI355X engine (default markov_chain_calibrate_orig only)"

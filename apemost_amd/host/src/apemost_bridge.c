@@ -161,6 +161,20 @@ static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned in
     cfg.sigma = SIGMA;
     cfg.hmin = HMIN;
     cfg.circular_params = circular_mask();
+    /* the reference's compile-time variants of the proposal, the swap schedule and the run loop */
+#ifdef PROPOSAL_LOGISTIC
+    cfg.flags |= APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC;
+#endif
+#ifdef PROPOSAL_UNIFORM
+    cfg.flags |= APEMOST_HIP_FLAG_PROPOSAL_UNIFORM;
+#endif
+#ifdef RANDOMSWAP
+    cfg.flags |= APEMOST_HIP_FLAG_RANDOMSWAP;
+#endif
+#ifdef ADAPT
+    cfg.flags |= APEMOST_HIP_FLAG_ADAPT;
+#endif
+    cfg.adapt_target = TARGET_ACCEPTANCE_RATE;
     apemost_hip_or_die(apemost_hip_create(&cfg, &s), "apemost_hip_create");
     if (m->data->tda != m->data->size2) {
         fprintf(stderr, "data matrix must be contiguous\n");

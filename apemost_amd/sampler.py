@@ -57,14 +57,15 @@ def calc_beta_0(state, chain, stepwidth_factors):
 class HipSampler:
     def __init__(self, model, n_par, n_chains, data, seed=0, device=0, chain_offset=0,
                  n_chains_global=None, waves_per_chain=0, sigma=0.5, hmin=1e-6, lds_policy=0, circular_params=0,
-                 flags=0):
+                 flags=0, adapt_target=0.0):
         data = np.ascontiguousarray(data, dtype=np.float64)
         assert data.ndim == 2
         self.cfg = capi.Config(abi_version=capi.ABI_VERSION, device=device, model=model, n_par=n_par,
                                n_chains=n_chains, n_data=data.shape[0], n_cols=data.shape[1],
                                waves_per_chain=waves_per_chain, lds_policy=lds_policy, chain_offset=chain_offset,
                                n_chains_global=n_chains if n_chains_global is None else n_chains_global,
-                               seed=seed, sigma=sigma, hmin=hmin, circular_params=circular_params, flags=flags)
+                               seed=seed, sigma=sigma, hmin=hmin, circular_params=circular_params, flags=flags,
+                               adapt_target=adapt_target)
         self._h = C.c_void_p()
         self.L = capi.lib()
         capi.check(self.L.apemost_hip_create(C.byref(self.cfg), C.byref(self._h)))
@@ -150,6 +151,10 @@ class HipSampler:
     def launch_rounds(self, n_rounds, n_steps, apply_swap, d_samples=0):
         self._adopt(d_samples)
         capi.check(self.L.apemost_hip_launch_rounds(self._h, n_rounds, n_steps, int(apply_swap), d_samples))
+
+    def swap_pair(self, round_):
+        """lower chain of the pair swap attempt `round_` picks under this sampler's swap schedule"""
+        return int(self.L.apemost_hip_sampler_swap_pair(self._h, round_))
 
     @property
     def max_rounds_per_launch(self):

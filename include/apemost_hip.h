@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APEMOST_HIP_ABI_VERSION 1
+#define APEMOST_HIP_ABI_VERSION 2
 
 enum {
     APEMOST_HIP_OK = 0,
@@ -68,7 +68,9 @@ enum {
 /* RNG addressing (rocRAND Philox4x32-10): stream (chain, slot) = subsequence chain*256+slot;
  * attempt q of parameter p's proposal at tick t = block (t<<24)|q of slot p, words 0,1;
  * accept uniform of tick t = word 0 of block t<<24 of slot n_par; swap attempt number r =
- * block r of the swap subsequence (word 0 pair choice, word 1 accept). */
+ * block r of the swap subsequence (word 0 pair choice, word 1 accept; with
+ * APEMOST_HIP_FLAG_RANDOMSWAP words 1 and 2, word 0 being the swap_probability draw).
+ * Non-Gaussian proposals read word 0 of the attempt's block. */
 #define APEMOST_HIP_STREAMS_PER_CHAIN 256
 #define APEMOST_HIP_TICK_SHIFT 24
 #define APEMOST_HIP_SWAP_SUBSEQUENCE 0x8000000000000000ULL
@@ -87,7 +89,25 @@ enum {
     /* stepping launches of workgroups with 8 likelihood waves use the classic two-phase step
      * (two barriers, the chain's wave alone between them) instead of the one-barrier kernel; same
      * chain either way (A/B comparisons, fallback) */
-    APEMOST_HIP_FLAG_TWO_BARRIER_STEP = 4
+    APEMOST_HIP_FLAG_TWO_BARRIER_STEP = 4,
+    /* the reference's compile-time variants (defaults: Gaussian proposal, decide_swap_now, no
+     * adaptation).  At most one of the two proposal bits.  The proposal and swap variants run in
+     * kernel instantiations of their own (the default kernels carry no test for them), built for
+     * 1, 2, 4 and 8 waves per chain. */
+    /* -DPROPOSAL_LOGISTIC: get_next_random_jump = gsl_ran_logistic(r, step),
+     * src/mcmc_gettersetter.c:291-292 (uniform of word 0 of the attempt's block) */
+    APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC = 8,
+    /* -DPROPOSAL_UNIFORM: gsl_ran_flat(r, -step, step), src/mcmc_gettersetter.c:293-294 */
+    APEMOST_HIP_FLAG_PROPOSAL_UNIFORM = 16,
+    /* -DRANDOMSWAP: tempering_interaction() goes through
+     * parallel_tempering_decide_swap_random(chains, n_beta, 1)
+     * (src/parallel_tempering_interaction.c:47-64, 130-131): one more uniform ahead of the pair
+     * choice -- swap attempt r reads words 0 (swap_probability), 1 (pair), 2 (accept) of block r */
+    APEMOST_HIP_FLAG_RANDOMSWAP = 32,
+    /* -DADAPT: adapt() after the steps of every round of a stepping launch
+     * (src/parallel_tempering.c:282-301, 404) nudges the chain's step widths by 0.99 or 1/0.99
+     * towards apemost_hip_config.adapt_target */
+    APEMOST_HIP_FLAG_ADAPT = 64
 };
 
 typedef struct {
@@ -108,6 +128,8 @@ typedef struct {
     double hmin;             /* HMIN, apps/pulse.c:8-10 */
     uint64_t circular_params; /* bit p set: parameter p wraps around [min,max] instead of being
                                * redrawn (-DCIRCULAR_PARAMS, src/markov_chain.c:241-265) */
+    double adapt_target;      /* TARGET_ACCEPTANCE_RATE (src/define_defaults.h:77-79) for
+                               * APEMOST_HIP_FLAG_ADAPT; 0 = the reference's default 0.5 */
 } apemost_hip_config;
 
 /* Host-side structure-of-arrays view of n_chains chains; any pointer may be NULL
@@ -236,6 +258,9 @@ int apemost_hip_host_free(void *p);
 /* pair index `a` that tempering_interaction() will pick at swap-stream position
  * `round` (parallel_tempering_decide_swap_now, interaction.c:87-97); -1 if n_global==1 */
 int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t n_chains_global);
+/* the same for this sampler's ladder and swap schedule (with APEMOST_HIP_FLAG_RANDOMSWAP the pair
+ * comes from word 1 of the block) */
+int64_t apemost_hip_sampler_swap_pair(const apemost_hip_sampler *s, uint64_t round);
 
 /* sharded ladders: the swap partner across a shard edge.  side 0 = lower
  * neighbour (chain_offset-1), 1 = upper neighbour.  A record is

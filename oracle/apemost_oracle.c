@@ -138,6 +138,55 @@ int orc_gaussian_attempt(uint64_t seed, uint64_t chain_global, int slot, uint64_
     return 1;
 }
 
+/* get_next_random_jump (src/mcmc_gettersetter.c:290-305) on the global stream.  GSL 1.x is not
+ * vendored in the reference; its published algorithms (randist/logistic.c, randist/flat.c):
+ *   gsl_ran_logistic(r, a): do x = gsl_rng_uniform_pos(r) while (x == 1); return a * log(x / (1 - x))
+ *   gsl_ran_flat(r, a, b):  u = gsl_rng_uniform(r); return a * (1 - u) + b * u                     */
+double orc_jump(orc_rng *r, double sigma, int proposal) {
+    if (proposal == ORC_PROPOSAL_LOGISTIC) {
+        double x, z;
+        do {
+            x = uniform_pos(r);
+        } while (x == 1);
+        z = log(x / (1 - x));
+        return sigma * z;
+    }
+    if (proposal == ORC_PROPOSAL_UNIFORM) {
+        const double u = orc_uniform(r);
+        return (-sigma) * (1 - u) + sigma * u;
+    }
+    return orc_gaussian(r, sigma);
+}
+
+/* The same three laws on a tick-addressed Philox block: attempt q of (chain, slot) at tick t.
+ * Returns 0 when the attempt's uniforms are rejected by the law itself (polar pair outside the
+ * unit disc, a zero word where GSL redraws); the caller then moves on to attempt q+1, which is
+ * the redraw GSL would make on a sequential stream.  The logistic law reads word 0 of the
+ * block, the flat law word 0 (it never rejects). */
+int orc_jump_attempt(uint64_t seed, uint64_t chain_global, int slot, uint64_t tick, uint64_t q,
+                     int proposal, double sigma, double *jump_out) {
+    if (proposal == ORC_PROPOSAL_GAUSSIAN) {
+        double y, sq;
+        if (!orc_gaussian_attempt(seed, chain_global, slot, tick, q, &y, &sq))
+            return 0;
+        *jump_out = sigma * y * sq;
+        return 1;
+    } else {
+        const uint64_t subseq = chain_global * ORC_STREAMS_PER_CHAIN + (uint64_t)slot;
+        const uint64_t block = (tick << ORC_TICK_SHIFT) | q;
+        const uint32_t w0 = orc_philox_at(seed, subseq, 4 * block + 0);
+        const double x = w0 / 4294967296.0;
+        if (proposal == ORC_PROPOSAL_LOGISTIC) {
+            if (w0 == 0)
+                return 0;
+            *jump_out = sigma * log(x / (1 - x));
+        } else {
+            *jump_out = (-sigma) * (1 - x) + sigma * x;
+        }
+        return 1;
+    }
+}
+
 /* get_next_alog_urandom (src/mcmc_gettersetter.c:307-309).  Real GSL aborts on
  * log(0) (quirk Q8); the restatement defines ln 0 = -inf. */
 double orc_accept_log_uniform(uint64_t seed, uint64_t chain_global, int n_par, uint64_t tick) {
@@ -304,23 +353,24 @@ static void do_step_for(orc_state *s, orc_rng *r, int c, int p) {
     const int circular = (int)((s->circular >> p) & 1);
     double new_value;
     if (r->kind == ORC_RNG_GLOBAL_MT) {
-        new_value = old_value + orc_gaussian(r, step);
+        new_value = old_value + orc_jump(r, step, s->proposal);
         if (new_value > max || new_value < min) {
             if (circular) {
                 new_value = min + orc_mod_double(new_value - min, max - min);
             } else {
                 do {
-                    new_value = old_value + orc_gaussian(r, step);
+                    new_value = old_value + orc_jump(r, step, s->proposal);
                 } while (new_value > max || new_value < min);
             }
         }
     } else {
         uint64_t q = 0;
         for (;; q++) {
-            double y, sq;
-            if (!orc_gaussian_attempt(r->seed, (uint64_t)(s->chain_offset + c), p, r->ticks[c], q, &y, &sq))
+            double jump;
+            if (!orc_jump_attempt(r->seed, (uint64_t)(s->chain_offset + c), p, r->ticks[c], q, s->proposal,
+                                  step, &jump))
                 continue;
-            new_value = old_value + step * y * sq;
+            new_value = old_value + jump;
             if (!(new_value > max || new_value < min))
                 break;
             if (circular) {
@@ -508,21 +558,32 @@ static void do_swap(orc_state *s, int a) {
  * Only valid when this state holds the whole ladder (chain_offset == 0). */
 int orc_tempering_interaction(orc_state *s, orc_rng *r, double *trace) {
     const int n_beta = s->n_chain;
-    double u, u2, c, rr = NAN;
+    double u0 = 0, u, u2, c, rr = NAN;
     int a, swapped = 0;
     if (r->kind == ORC_RNG_STREAMS) {
-        u = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 0) / 4294967296.0;
-        u2 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 1) / 4294967296.0;
+        const int k = s->randomswap ? 1 : 0; /* word 0 is then the swap_probability draw */
+        u0 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 0) / 4294967296.0;
+        u = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + k) / 4294967296.0;
+        u2 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + k + 1) / 4294967296.0;
         r->round++;
         if (n_beta == 1)
             return -1;
     } else {
         if (n_beta == 1)
             return -1;
+        if (s->randomswap)
+            u0 = orc_uniform(r);
+        if (s->randomswap && !(u0 < 1.0 / 1))
+            return -1; /* before the pair is drawn, :56-57 */
         u = orc_mt_next(&r->mt) / 4294967296.0;
         u2 = orc_mt_next(&r->mt) / 4294967296.0;
         r->draws += 2;
     }
+    /* -DRANDOMSWAP: parallel_tempering_decide_swap_random(chains, n_beta, 1), :47-64: one more
+     * uniform first, compared with 1.0 / n_swap where the caller passes n_swap = 1 (:131); the
+     * partner is (a + 1) % n_beta = a + 1 because a < n_beta - 1 */
+    if (s->randomswap && !(u0 < 1.0 / 1))
+        return -1;
     a = orc_swap_pair_index(u, n_beta);
     c = (u2 > 0) ? log(u2) : -INFINITY;
     swapped = orc_swap_decision(s->beta[a], s->beta[a + 1], s->prob[a], s->prob[a + 1], c, &rr);
@@ -583,15 +644,21 @@ int orc_tempering_interaction_shard(orc_state *s, orc_rng *r, int64_t n_global, 
                                     const double *halo_hi, int *swapped_out) {
     const int n = s->n_par;
     const int64_t lo = s->chain_offset, hi = s->chain_offset + s->n_chain;
-    double u, u2, c, rr;
+    double u0, u, u2, c, rr;
     int64_t a;
     int swapped = 0;
     if (swapped_out)
         *swapped_out = 0;
-    u = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 0) / 4294967296.0;
-    u2 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 1) / 4294967296.0;
+    {
+        const int k = s->randomswap ? 1 : 0;
+        u0 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + 0) / 4294967296.0;
+        u = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + k) / 4294967296.0;
+        u2 = orc_philox_at(r->seed, ORC_SWAP_SUBSEQUENCE, 4 * r->round + k + 1) / 4294967296.0;
+    }
     r->round++;
     if (n_global <= 1)
+        return -1;
+    if (s->randomswap && !(u0 < 1.0 / 1))
         return -1;
     a = orc_swap_pair_index(u, (int)n_global);
     c = (u2 > 0) ? log(u2) : -INFINITY;
@@ -628,6 +695,33 @@ int orc_tempering_interaction_shard(orc_state *s, orc_rng *r, int64_t n_global, 
     return (int)a;
 }
 
+/* adapt() with -DADAPT (src/parallel_tempering.c:282-301), called once per round between the
+ * n_swap steps and tempering_interaction (:404): the ratio is accepts / REJECTS (not / total),
+ * both summed over the parameters (src/mcmc_gettersetter.c:25-41); all step widths of the chain
+ * scale by 0.99 or by the double 1 / 0.99; past 100000 counted updates the counters restart */
+void orc_adapt(orc_state *s, int c) {
+    const int n = s->n_par;
+    uint64_t acc = 0, rej = 0;
+    double ratio;
+    int p;
+    for (p = 0; p < n; p++) {
+        acc += s->params_accepts[(size_t)c * n + p];
+        rej += s->params_rejects[(size_t)c * n + p];
+    }
+    if (acc + rej < 20000)
+        return;
+    ratio = acc * 1.0 / rej;
+    if (ratio < s->adapt_target - 0.05) {
+        for (p = 0; p < n; p++)
+            s->step[(size_t)c * n + p] *= 0.99;
+    } else if (ratio > s->adapt_target + 0.05) {
+        for (p = 0; p < n; p++)
+            s->step[(size_t)c * n + p] *= 1 / 0.99;
+    }
+    if (acc + rej > 100000)
+        orc_reset_accept_rejects(s, c);
+}
+
 void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n_swap,
                      double *samples, int n_threads) {
     uint64_t round;
@@ -648,6 +742,9 @@ void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n
             for (c = 0; c < s->n_chain; c++)
                 run_chain_round(s, r, c, round, n_swap, samples);
         }
+        if (s->adapt)
+            for (c = 0; c < s->n_chain; c++)
+                orc_adapt(s, c);
         orc_tempering_interaction(s, r, NULL);
     }
 }

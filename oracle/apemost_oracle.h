@@ -62,6 +62,10 @@ enum {
  */
 enum { ORC_RNG_GLOBAL_MT = 0, ORC_RNG_STREAMS = 1 };
 
+/* proposal distribution: default gsl_ran_gaussian, -DPROPOSAL_LOGISTIC gsl_ran_logistic(sigma),
+ * -DPROPOSAL_UNIFORM gsl_ran_flat(-sigma, sigma)  (src/mcmc_gettersetter.c:290-305) */
+enum { ORC_PROPOSAL_GAUSSIAN = 0, ORC_PROPOSAL_LOGISTIC = 1, ORC_PROPOSAL_UNIFORM = 2 };
+
 typedef struct {
     uint32_t mt[624];
     int mti;
@@ -114,6 +118,11 @@ typedef struct {
     uint64_t *reject;       /* [n_chain] */
     uint64_t *n_iter;       /* [n_chain] */
     uint64_t *swapcount;    /* [n_chain] */
+    /* compile-time variants of the reference, 0 = its defaults */
+    int proposal;           /* ORC_PROPOSAL_*: get_next_random_jump, src/mcmc_gettersetter.c:290-305 */
+    int randomswap;         /* -DRANDOMSWAP, src/parallel_tempering_interaction.c:130-131 */
+    int adapt;              /* -DADAPT, src/parallel_tempering.c:282-301 */
+    double adapt_target;    /* TARGET_ACCEPTANCE_RATE, src/define_defaults.h:77-79 */
 } orc_state;
 
 /* calibration knobs (src/define_defaults.h:24-86, src/markov_chain.h:25-32) */
@@ -142,6 +151,11 @@ double orc_gaussian(orc_rng *r, double sigma);
  * pair is usable; then the N(0,sigma) variate is (sigma*y)*s_out */
 int orc_gaussian_attempt(uint64_t seed, uint64_t chain_global, int slot, uint64_t tick, uint64_t q,
                          double *y_out, double *s_out);
+/* get_next_random_jump for the three proposal laws: on the global stream, and as attempt q of a
+ * tick-addressed stream (returns 0 if the law rejects the attempt's uniforms) */
+double orc_jump(orc_rng *r, double sigma, int proposal);
+int orc_jump_attempt(uint64_t seed, uint64_t chain_global, int slot, uint64_t tick, uint64_t q,
+                     int proposal, double sigma, double *jump_out);
 double orc_accept_log_uniform(uint64_t seed, uint64_t chain_global, int n_par, uint64_t tick);
 
 double orc_loglike(int model, int n_par, const double *params, const double *data,
@@ -177,6 +191,10 @@ int orc_tempering_interaction_shard(orc_state *s, orc_rng *r, int64_t n_global, 
                                     const double *halo_hi, int *swapped_out);
 /* n_steps x {markov_chain_step, check_best, n_iter++} for every local chain, no swap */
 void orc_run_steps(orc_state *s, orc_rng *r, unsigned int n_steps, double *samples, int n_threads);
+
+/* -DADAPT step-width nudging of one chain at the end of a round (orc_run_sampler calls it for
+ * every chain when s->adapt is set) */
+void orc_adapt(orc_state *s, int chain);
 
 /* samples: [n_rounds*n_swap][n_chain][n_par+2] = params.., prob, prob-prior ; may be NULL.
  * n_threads > 1 is only meaningful with ORC_RNG_STREAMS. */

@@ -15,6 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libapemost_oracle.so")
 
 MODEL_SIMPLESIN, MODEL_PULSE, MODEL_PULSE_VROT, MODEL_SINE3 = 0, 1, 2, 3
 RNG_GLOBAL_MT, RNG_STREAMS = 0, 1
+PROPOSAL_GAUSSIAN, PROPOSAL_LOGISTIC, PROPOSAL_UNIFORM = 0, 1, 2
 (LADDER_CHEBYSHEV_BETA, LADDER_EQUIDISTANT_BETA, LADDER_EQUIDISTANT_TEMPERATURE,
  LADDER_CHEBYSHEV_TEMPERATURE, LADDER_EQUIDISTANT_STEPWIDTH, LADDER_CHEBYSHEV_STEPWIDTH,
  LADDER_HOT_CHAINS) = range(7)
@@ -40,7 +41,9 @@ class _State(C.Structure):
                 ("params", _dp), ("params_best", _dp), ("step", _dp), ("pmin", _dp),
                 ("pmax", _dp), ("params_accepts", _up), ("params_rejects", _up),
                 ("beta", _dp), ("prob", _dp), ("prior", _dp), ("prob_best", _dp),
-                ("accept", _up), ("reject", _up), ("n_iter", _up), ("swapcount", _up)]
+                ("accept", _up), ("reject", _up), ("n_iter", _up), ("swapcount", _up),
+                ("proposal", C.c_int), ("randomswap", C.c_int), ("adapt", C.c_int),
+                ("adapt_target", C.c_double)]
 
 
 class CalibCfg(C.Structure):
@@ -83,6 +86,12 @@ def lib():
         L.orc_gaussian.restype = C.c_double
         L.orc_gaussian_attempt.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, _dp, _dp]
         L.orc_gaussian_attempt.restype = C.c_int
+        L.orc_jump.argtypes = [C.POINTER(_Rng), C.c_double, C.c_int]
+        L.orc_jump.restype = C.c_double
+        L.orc_jump_attempt.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                       C.c_double, _dp]
+        L.orc_jump_attempt.restype = C.c_int
+        L.orc_adapt.argtypes = [C.POINTER(_State), C.c_int]
         L.orc_accept_log_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.orc_accept_log_uniform.restype = C.c_double
         L.orc_loglike.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
@@ -159,6 +168,11 @@ class Ladder:
         self.chain_offset = int(chain_offset)
         self.sigma, self.hmin = float(sigma), float(hmin)
         self.circular = 0   # bit p: parameter p wraps (CIRCULAR_PARAMS)
+        # the reference's compile-time variants (0 = default build)
+        self.proposal = PROPOSAL_GAUSSIAN   # -DPROPOSAL_LOGISTIC / -DPROPOSAL_UNIFORM
+        self.randomswap = 0                 # -DRANDOMSWAP
+        self.adapt = 0                      # -DADAPT
+        self.adapt_target = 0.5             # TARGET_ACCEPTANCE_RATE
         z2 = lambda dt: np.zeros((n_chain, n_par), dtype=dt)
         z1 = lambda dt: np.zeros((n_chain,), dtype=dt)
         self.params, self.params_best, self.step = z2(np.float64), z2(np.float64), z2(np.float64)
@@ -196,6 +210,8 @@ class Ladder:
         st.data = self.data.ctypes.data_as(_dp)
         st.sigma, st.hmin = self.sigma, self.hmin
         st.circular = self.circular
+        st.proposal, st.randomswap, st.adapt = int(self.proposal), int(self.randomswap), int(self.adapt)
+        st.adapt_target = float(self.adapt_target)
         for n in _F64:
             a = getattr(self, n)
             assert a.flags.c_contiguous and a.dtype == np.float64, n
@@ -253,6 +269,12 @@ def gaussian_attempt(seed, chain_global, slot, tick, q):
     y, sq = C.c_double(0), C.c_double(0)
     ok = lib().orc_gaussian_attempt(seed, chain_global, slot, tick, q, C.byref(y), C.byref(sq))
     return bool(ok), y.value, sq.value
+
+
+def jump_attempt(seed, chain_global, slot, tick, q, proposal, sigma):
+    j = C.c_double(0)
+    ok = lib().orc_jump_attempt(seed, chain_global, slot, tick, q, proposal, sigma, C.byref(j))
+    return bool(ok), j.value
 
 
 def accept_log_uniform(seed, chain_global, n_par, tick):

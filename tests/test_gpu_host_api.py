@@ -404,3 +404,72 @@ def test_run_shards_abi_equals_whole_ladder_and_oracle():
     assert rc == capi.ERR_INVALID
     for s in shards:
         s.close()
+
+
+def test_c_application_built_with_the_variant_macros_equals_python_mirror_and_oracle(tmp_path):
+    """-DPROPOSAL_LOGISTIC -DRANDOMSWAP -DADAPT on the application's compile line (the reference's own
+    knobs, src/mcmc_gettersetter.c:290-305, parallel_tempering_interaction.c:130-131,
+    parallel_tempering.c:282-301) reach the engine as apemost_hip_config.flags: the three phases of
+    the C application equal the Python mirror created with the same flags, and the run phase equals
+    the oracle's"""
+    from apemost_amd import capi
+    from apemost_amd.sampler import HipSampler
+    from apemost_amd.state import LadderState
+    import torch
+    n_beta, burn, iters = 8, 800, 8000                # 32 rounds of 250; ADAPT starts after 5000 steps
+    w = wl.simplesin(n_data=128, n_chain=n_beta)
+    work = tmp_path / "w"
+    _inputs(work, w)
+    exe = hostlib.make(str(tmp_path / "sine.exe"),
+                       ccflags="-DN_BETA=%d -DBURN_IN_ITERATIONS=%d -DMAX_ITERATIONS=%d -DPROPOSAL_LOGISTIC -DRANDOMSWAP "
+                               "-DADAPT -DTARGET_ACCEPTANCE_RATE=0.4" % (n_beta, burn, iters))
+    env = dict(os.environ, APEMOST_SEED="7")
+    for phase in ("calibrate_first", "calibrate_rest", "run"):
+        subprocess.check_call([exe, phase], cwd=str(work), env=env, stdout=subprocess.DEVNULL)
+    c_calib = (work / "calibration_results").read_text()
+    c_amp = np.loadtxt(str(work / "amplitude-chain-0.prob.dump"))
+    c_accept = (work / "acceptance_rate.dump").read_text().strip().splitlines()[-1].split()
+
+    flags = capi.FLAG_PROPOSAL_LOGISTIC | capi.FLAG_RANDOMSWAP | capi.FLAG_ADAPT
+    data = np.loadtxt(str(work / "data"))
+    dcfg = capi.calib_defaults(burn_in_iterations=burn, rat_limit=0.4, target_global=0.4)
+    mk = lambda: LadderState.from_params(n_beta, _rt(w.start), _rt(w.pmin), _rt(w.pmax), _rt(w.step))
+    s = HipSampler(w.model, 4, 1, data, seed=7, flags=flags, adapt_target=0.4)
+    s.set_state(mk().slice(0, 1))
+    assert s.calibrate_first(dcfg) == 0
+    first = s.get_state()
+    s.close()
+    s = HipSampler(w.model, 4, n_beta, data, seed=7, flags=flags, adapt_target=0.4)
+    st = mk()
+    st.beta[0], st.step[0], st.params[0] = _rt(first.beta[0]), _rt(first.step[0]), _rt(first.params[0])
+    st.params_best[0] = st.params[0]
+    s.set_state(st)
+    status, beta_0, _ = s.calibrate_rest(dcfg)
+    assert status == 0
+    assert s.get_state().calibration_results_text() == c_calib
+    s.close()
+
+    s = HipSampler(w.model, 4, n_beta, data, seed=7, flags=flags, adapt_target=0.4)
+    st = mk()
+    st.read_calibration_results(c_calib)
+    s.set_state(st)
+    n_swap = 2000 // n_beta
+    d = torch.zeros((iters, n_beta, 6), dtype=torch.float64, device="cuda")
+    s.run_sampler(iters // n_swap, n_swap, d.data_ptr())
+    s.synchronize()
+    run = s.get_state()
+    s.close()
+    samples = d.cpu().numpy()
+    assert np.array_equal(c_amp, _rt(samples[:, 0, 0]))
+    assert [int(t) for t in c_accept] == [iters] + [int(a) for a in run.accept]
+    assert not np.allclose(run.step, st.step)          # adapt() moved the widths during the run
+
+    lad = orc.Ladder(w.model, n_beta, 4, data)
+    for n in ("params", "params_best", "step", "pmin", "pmax", "beta"):
+        getattr(lad, n)[...] = getattr(st, n)
+    lad.proposal, lad.randomswap, lad.adapt, lad.adapt_target = orc.PROPOSAL_LOGISTIC, 1, 1, 0.4
+    rng = orc.Rng(orc.RNG_STREAMS, 7, lad)
+    ref = orc.run_sampler(lad, rng, iters // n_swap, n_swap, record=True, n_threads=8)
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(run.step, lad.step, rtol=1e-12)
+    assert np.array_equal(run.accept, lad.accept) and np.array_equal(run.swapcount, lad.swapcount)

@@ -42,6 +42,21 @@ def test_example_app_builds_strict(tmp_path):
     assert os.path.exists(exe)
 
 
+def test_variant_macros_build_strict_and_rwm_is_refused(tmp_path):
+    """the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP,
+    -DADAPT) are accepted on the application's compile line (the bridge turns them into engine
+    flags); -DRWM, which the reference itself cannot compile, stops the build with a message"""
+    build.build_hip()
+    for flags in ("-DPROPOSAL_LOGISTIC -DRANDOMSWAP -DADAPT -DTARGET_ACCEPTANCE_RATE=0.4", "-DPROPOSAL_UNIFORM"):
+        assert os.path.exists(_make(str(tmp_path / "v.exe"), ccflags="-DN_BETA=4 " + flags))
+        os.remove(str(tmp_path / "v.exe"))
+    for flags in ("-DRWM", "-DPROPOSAL_LOGISTIC -DPROPOSAL_UNIFORM"):
+        with pytest.raises(subprocess.CalledProcessError):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apemost_amd", "host"),
+                                   "OUT=" + str(tmp_path / "no.exe"), "CCFLAGS=-DN_BETA=4 " + flags],
+                                  stderr=subprocess.DEVNULL)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 def test_reference_apps_link_unchanged_and_eval_matches_manual(tmp_path):
     build.build_hip()
