@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Accuracy of the device sine (pt_device.h: sin_cw, Cody-Waite reduction modulo pi + one odd
-polynomial on [-pi/2, pi/2]) against 200-bit arithmetic, operation by operation as the kernel
-rounds them (every FMA rounds once).  Compares the two evaluation orders of the polynomial:
+"""Accuracy of the device sine (pt_device.h: sin_cw, two-term Cody-Waite reduction modulo pi + one
+odd polynomial on [-pi/2, pi/2]) against 200-bit arithmetic, operation by operation as the kernel
+rounds them (every FMA rounds once).  Reports the absolute error (what a likelihood sees: it adds
+a sin() to numbers of order one) and the relative error in ulp, for the kernel's two-term
+reduction and for a three-term one (which keeps the relative error near the zeros of the sine at
+the price of one more FMA per sine), and compares the two evaluation orders of the polynomial:
 Horner (shortest instruction count) and Estrin (shortest dependent chain).
 
     python tools/check_sine.py [samples]"""
@@ -23,7 +26,7 @@ def fma(a, b, c):
     return float(mp.mpf(a) * mp.mpf(b) + mp.mpf(c))
 
 
-def reduce_(x, terms=3):
+def reduce_(x, terms=2):
     fm = fma(x, INV_PI, MAGIC)
     fn = fm - MAGIC
     r = fma(fn, NPI_HI, x)
@@ -33,7 +36,7 @@ def reduce_(x, terms=3):
     return r, int(fn) & 1
 
 
-def horner(x, terms=3):
+def horner(x, terms=2):
     r, odd = reduce_(x, terms)
     z = r * r
     q = fma(z, S[7], S[6])
@@ -43,7 +46,7 @@ def horner(x, terms=3):
     return -v if odd else v
 
 
-def estrin(x, terms=3):
+def estrin(x, terms=2):
     r, odd = reduce_(x, terms)
     z = r * r
     z2 = z * z
@@ -67,23 +70,33 @@ def ulp_err(got, x):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     rnd = random.Random(1)
-    worst = {"horner": 0.0, "estrin": 0.0, "estrin2": 0.0}
+    worst = {"abs2": 0.0, "ulp2": 0.0, "ulp2_away": 0.0, "ulp3": 0.0, "estrin_abs2": 0.0, "estrin_ulp3": 0.0}
     for i in range(n):
-        kind = i % 4
+        kind = i % 5
         if kind == 0:
             x = rnd.uniform(-10, 10)
         elif kind == 1:
             x = rnd.uniform(-1e4, 1e4)
         elif kind == 2:
-            x = rnd.choice((-1, 1)) * 10 ** rnd.uniform(0, 13)
-        else:  # neighbourhoods of k pi / 2
+            x = rnd.choice((-1, 1)) * 10 ** rnd.uniform(0, 13.5)
+        elif kind == 3:  # neighbourhoods of k pi / 2
             x = float(mp.mpf(rnd.randrange(-100000, 100000)) * mp.pi / 2) + rnd.uniform(-1e-6, 1e-6)
-        worst["horner"] = max(worst["horner"], ulp_err(horner(x), x))
-        worst["estrin"] = max(worst["estrin"], ulp_err(estrin(x), x))
-        if abs(x) < 1e5:
-            worst["estrin2"] = max(worst["estrin2"], ulp_err(estrin(x, 2), x))
-    print("max error over %d samples (ulp): Horner %.3f, Estrin %.3f, Estrin with two-term reduction (|x| < 1e5) %.3f"
-          % (n, worst["horner"], worst["estrin"], worst["estrin2"]))
+        else:  # the doubles nearest to k pi: the worst cancellation the reduction can meet
+            x = float(mp.mpf(rnd.randrange(1, 10 ** rnd.randrange(1, 13))) * mp.pi)
+        ref = mp.sin(mp.mpf(x))
+        h2, h3 = horner(x, 2), horner(x, 3)
+        worst["abs2"] = max(worst["abs2"], float(abs(mp.mpf(h2) - ref)))
+        worst["ulp2"] = max(worst["ulp2"], ulp_err(h2, x))
+        if abs(ref) > 1e-6:
+            worst["ulp2_away"] = max(worst["ulp2_away"], ulp_err(h2, x))
+        worst["ulp3"] = max(worst["ulp3"], ulp_err(h3, x))
+        worst["estrin_abs2"] = max(worst["estrin_abs2"], float(abs(mp.mpf(estrin(x, 2)) - ref)))
+        worst["estrin_ulp3"] = max(worst["estrin_ulp3"], ulp_err(estrin(x, 3), x))
+    print("max error over %d samples, |x| < 3e13" % n)
+    print("  kernel (two-term reduction, Horner): absolute %.3g; relative %.3g ulp where |sin| > 1e-6, %.3g ulp anywhere"
+          % (worst["abs2"], worst["ulp2_away"], worst["ulp2"]))
+    print("  three-term reduction, Horner: %.3g ulp anywhere" % worst["ulp3"])
+    print("  Estrin: absolute %.3g (two-term), %.3g ulp (three-term)" % (worst["estrin_abs2"], worst["estrin_ulp3"]))
 
 
 if __name__ == "__main__":
