@@ -71,6 +71,9 @@ class ShardedLadder:
         if self.dist is None or self.world == 1:
             return
         dist = self.dist
+        # c10d: batched P2P among a subset of the ranks is defined only after the group's first
+        # collective, which every rank must take part in
+        dist.barrier()
         with self.e.comm_stream():
             for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
                 if peer < 0 or peer >= self.world:
