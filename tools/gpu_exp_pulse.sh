@@ -1,0 +1,15 @@
+#!/bin/bash
+set -o pipefail
+out=gpurun_out/r02pulse
+mkdir -p $out
+run() { # tag lib args...
+  local tag=$1 lib=$2; shift 2
+  APEMOST_HIP_LIB=$lib timeout -k 10 150 python bench.py --cpu-seconds 0 --burn-in 200 "$@" > $out/b_$tag.log 2>&1 || { echo "$tag failed"; tail -5 $out/b_$tag.log; exit 1; }
+  echo "$tag $(tail -n 1 $out/b_$tag.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("%.4g"%d["value"], d["config"]["waves_per_chain"])')"
+}
+run c4_tab $PWD/tmp_exp/pulse_logtab.so --config 4
+run c4_ocml $PWD/apemost_amd/libapemost_hip.so --config 4
+run c4w_tab $PWD/tmp_exp/pulse_logtab.so --config 4 --chains-per-gpu 2048
+run c4w_ocml $PWD/apemost_amd/libapemost_hip.so --config 4 --chains-per-gpu 2048
+run c4_tab $PWD/tmp_exp/pulse_logtab.so --config 4
+run c4_ocml $PWD/apemost_amd/libapemost_hip.so --config 4
