@@ -37,11 +37,18 @@ __host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? wav
 // candidate production as a side duty of waves 1-3 (workgroups of at least 4 waves)
 // (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
 __host__ __device__ constexpr bool has_producer(int waves) { return waves >= 4; }
-// The one-barrier round kernel (pt_onebarrier.h) is used with 8 likelihood waves per chain (ladders
-// of up to 128 chains).  With 4 (129-512 chains) it was measured 3 % behind the classic kernel on
-// config 4's shard (256 pulse chains x 1024 points: 6.9e7 vs 7.1e7 steps/s): one likelihood wave per
-// SIMD leaves the chain's wave enough issue slots in the classic kernel too.
-__host__ __device__ constexpr bool has_one_barrier(int waves) { return waves == 8; }
+// The one-barrier round kernel (pt_onebarrier.h) exists for 4 and 8 likelihood waves per chain
+// (+ owner + three candidate producers: workgroups of 8 and 12 waves).  Measured on one MI355X
+// (steps/s, one-barrier 4 / one-barrier 8 / two-phase 4; tools/gpu_exp_ob4.sh):
+//   simplesin  128 x  1024 (n_swap 15): 1.85e8 / 1.66e8 / 1.27e8     64 x 1024: 0.99e8 / 0.88e8
+//   simplesin  256 x  1024 (n_swap  7): 3.18e8 / 1.67e8 / 2.37e8     128 x 4096: 9.2e7 / 8.8e7
+//   pulse      256 x  1024 (n_swap  1): 7.84e7 /   -    / 7.81e7     128 x 16384: 2.43e7 / 2.60e7
+//   pulse      256 x  1024 (n_swap  7): 1.19e8 / 0.89e8 / 1.04e8     128 x 65536: 6.7e6 / 7.2e6
+// With 2 it loses to 4 (128 x 1024: 1.48e8): the data vector no longer fits the registers.
+#ifndef APEMOST_OB_WAVES_MASK
+#define APEMOST_OB_WAVES_MASK 0x110
+#endif
+__host__ __device__ constexpr bool has_one_barrier(int waves) { return (APEMOST_OB_WAVES_MASK >> waves) & 1; }
 __host__ __device__ constexpr int block_threads(int waves, bool) { return waves * kWave; }
 
 template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
@@ -946,7 +953,11 @@ static int choose_waves(const apemost_hip_config &c) {
     // (sine3 1024 x 8192: 3.5e7 with 1 wave, 3.1e7 with 2; pulse_vrot 2048 x 65536: 4.2 / 3.9 / 4.0 /
     // 3.5 e6.)  A chain's step is a latency chain: while CUs are idle more waves per chain shorten
     // it; once every SIMD has a wave, a chain per wave without barriers does more.
-    int by_chip = c.n_chains <= 128 ? 8 : c.n_chains <= 512 ? 4 : c.n_chains < 1024 ? 2 : 1;
+    // Since the one-barrier kernel (see has_one_barrier): four likelihood waves per chain up to 512
+    // chains -- two waves per SIMD with the owner and the producers, no likelihood wave waits for a
+    // sibling on its SIMD -- and eight only where a step is long enough to be bound by issue rather
+    // than by the chain of dependent operations (>= 8192 points at <= 128 chains).
+    int by_chip = (c.n_chains <= 128 && c.n_data >= 8192) ? 8 : c.n_chains <= 512 ? 4 : c.n_chains < 1024 ? 2 : 1;
     // never fewer than 2 data points per lane
     int by_data = 1;
     while (by_data < 8 && c.n_data >= by_data * 2 * kWave * 2)

@@ -233,7 +233,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": traffic_profiled,
                      "limited_by": "fp64 issue / dependent-operation latency (data vector resident in LDS or L2)",
-                     "kernel": "pt_round_ob_kernel" if (waves == 8 and not (a.flags & 4)) else "pt_round_kernel", "launch_us": launch_ms * 1e3,
+                     "kernel": "pt_round_ob_kernel" if (waves in (4, 8) and not (a.flags & 4)) else "pt_round_kernel", "launch_us": launch_ms * 1e3,
                      "algorithmic_bytes_per_launch": bytes_per_step * steps_per_launch,
                      "fp64_valu_frac": flops_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e12
                                        / FP64_VALU_PEAK_TF},

@@ -1,4 +1,4 @@
-"""The one-barrier round kernel (apemost_amd/csrc/pt_onebarrier.h: 8 likelihood waves + owner
+"""The one-barrier round kernel (apemost_amd/csrc/pt_onebarrier.h: 4 or 8 likelihood waves + owner
 + candidate producer, accept test as a threshold on the data sum, both next proposals prepared
 ahead) against the classic two-phase kernel and against the oracle.  The two kernels make the same
 draws and add the data sum in the same order, so their chains are bit-identical (the accept
@@ -33,7 +33,7 @@ def _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=0, pieces=None, **
 
 
 @pytest.mark.parametrize("name", ["simplesin", "sine3", "pulse", "pulse_vrot"])
-@pytest.mark.parametrize("waves", [8])
+@pytest.mark.parametrize("waves", [4, 8])
 def test_one_barrier_equals_two_phase_kernel_and_oracle(name, waves):
     w = small_workloads()[name]
     n_chain, n_rounds, n_swap, seed = 8, 60, 11, 97
@@ -49,22 +49,23 @@ def test_one_barrier_equals_two_phase_kernel_and_oracle(name, waves):
     assert a.swapcount.sum() > 0 and 0 < a.accept.sum() < a.n_iter.sum()
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("n_swap", [1, 2, 15])
-def test_one_barrier_round_shapes(n_swap):
+def test_one_barrier_round_shapes(n_swap, waves):
     """rounds of one step (a barrier at the round start, one per step), of two, of many; launches cut
     at arbitrary rounds; single-round launches (every swap fused into the next launch's start)"""
     w = wl.simplesin(n_data=1024, n_chain=16)        # one pass of the data per lane: rows in registers
     n_chain, n_rounds, seed = 16, 90, 5
     st, lad, rng = make_pair(w, n_chain, seed=seed)
-    a, sa = _run(w, st, n_chain, n_rounds, n_swap, 8, seed, lds_policy=1)
-    b, sb = _run(w, st, n_chain, n_rounds, n_swap, 8, seed, pieces=(1, 7, 40, 42))
-    c, sc = _run(w, st, n_chain, n_rounds, n_swap, 8, seed, flags=capi.FLAG_SINGLE_ROUND_LAUNCHES)
+    a, sa = _run(w, st, n_chain, n_rounds, n_swap, waves, seed, lds_policy=1)
+    b, sb = _run(w, st, n_chain, n_rounds, n_swap, waves, seed, pieces=(1, 7, 40, 42))
+    c, sc = _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=capi.FLAG_SINGLE_ROUND_LAUNCHES)
     for other, so in ((b, sb), (c, sc)):
         for f in FIELDS:
             assert np.array_equal(getattr(a, f), getattr(other, f)), f
         assert np.array_equal(sa, so)
     ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True, n_threads=8)
-    assert_match(a, lad, rng, what="round shape %d" % n_swap)
+    assert_match(a, lad, rng, what="round shape %d waves %d" % (n_swap, waves))
     np.testing.assert_allclose(sa, ref, rtol=1e-9, atol=1e-300)
 
 
@@ -78,7 +79,7 @@ def test_one_barrier_redraw_path_and_circular_parameters():
         st.step[:] = (w.pmax - w.pmin) * 6.0
         lad.step[:] = st.step
         lad.circular = circular
-        for waves in (8,):
+        for waves in (4, 8):
             dev, samples = _run(w, st, 4, 12, 5, waves, 3, circular_params=circular)
             lad2 = orc.Ladder(w.model, 4, 4, w.data)
             to_oracle(st, lad2)
@@ -108,17 +109,23 @@ def test_one_barrier_maximum_parameter_count():
     w.pmax = np.array([50, 1] + [v for _ in modes for v in (12, 20)], float)
     w.step = (w.pmax - w.pmin) * 0.02
     st, lad, rng = make_pair(w, 3, seed=42)
-    dev, samples = _run(w, st, 3, 6, 4, 8, 42)
-    ref = orc.run_sampler(lad, rng, 6, 4, record=True)
-    assert_match(dev, lad, rng, what="62 parameters")
-    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    for waves in (4, 8):
+        st, lad, rng = make_pair(w, 3, seed=42)
+        dev, samples = _run(w, st, 3, 6, 4, waves, 42)
+        ref = orc.run_sampler(lad, rng, 6, 4, record=True)
+        assert_match(dev, lad, rng, what="62 parameters waves %d" % waves)
+        np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
 
 
 def test_one_barrier_config2_bench_shape_matches_oracle():
-    """BASELINE config 2 as bench.py runs it: 128 chains x 1024 points, 8 likelihood waves, rows in
-    registers, 32 rounds x 15 steps per launch with the swaps handed over inside the launch"""
+    """BASELINE config 2 as bench.py runs it: 128 chains x 1024 points, the engine's own choice of
+    workgroup (4 likelihood waves, rows in registers), 32 rounds x 15 steps per launch with the swaps
+    handed over inside the launch"""
     w = wl.simplesin(n_data=1024, n_chain=128)
     st, lad, rng = make_pair(w, 128, seed=7)
+    probe = HipSampler(w.model, w.n_par, 128, w.data)
+    assert probe.geometry == (4, True)
+    probe.close()
     dev, samples = _run(w, st, 128, 64, 15, 0, 7)
     ref = orc.run_sampler(lad, rng, 64, 15, record=True, n_threads=8)
     assert_match(dev, lad, rng, what="config 2")

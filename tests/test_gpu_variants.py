@@ -33,8 +33,8 @@ def _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=0, **kw):
                                         ("pulse", 8), ("pulse", 1), ("pulse_vrot", 4), ("pulse_vrot", 8)])
 def test_proposal_laws_match_oracle(law, name, waves):
     """run_sampler under a non-Gaussian proposal: the classic kernels (their own candidate refill at
-    1-2 waves, producer waves at 4) and the one-barrier kernel (8 waves; also forced back to the
-    two-phase step) against the oracle's do_step_for with the same law"""
+    1-2 waves) and the one-barrier kernel (4 and 8 waves; also forced back to the two-phase step with
+    its producer waves) against the oracle's do_step_for with the same law"""
     flag, kind = LAWS[law]
     w = small_workloads()[name]
     n_chain, n_rounds, n_swap, seed = 8, 40, 9, 61
@@ -45,7 +45,7 @@ def test_proposal_laws_match_oracle(law, name, waves):
     assert_match(dev, lad, rng, what="%s %s waves=%d" % (law, name, waves))
     np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
     assert 0 < dev.accept.sum() < dev.n_iter.sum()
-    if waves == 8:
+    if waves in (4, 8):
         two, s2 = _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=flag | capi.FLAG_TWO_BARRIER_STEP)
         assert np.array_equal(two.params, dev.params) and np.array_equal(s2, samples)
 
