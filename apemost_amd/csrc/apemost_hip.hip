@@ -402,27 +402,57 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(co
 #define OB_STAMP_FLUSH
 #endif
 
+// The rounds base .. base+63 of this launch whose opening swap attempt involves chain c (bit r - base):
+// lane l draws the pair of round base + l from the replicated swap stream.  A swap attempt touches
+// its two chains only (src/parallel_tempering_interaction.c:99-141): for every other chain the
+// boundary between two rounds is no event at all, and its pipeline of prepared proposals runs
+// through it.  Every wave of the workgroup evaluates this for itself (one Philox block per 64
+// rounds), so that all of them agree on where the extra barriers are.  Bit 0 of the launch's first
+// block is always set: the pipeline starts there.
+template <class E>
+__device__ __forceinline__ u64 rounds_restarting(const E &e, const RoundArgs &a, int c, unsigned base) {
+    bool involved = false;
+    const unsigned r = base + (unsigned)e.lane;
+    if (a.sh.n_global > 1 && r >= 1 && r < a.n_rounds) {
+        double u_accept;
+        const long long pair = swap_draws<E::kVariants>(a.sh, a.round + r - (a.apply_swap ? 0 : 1), u_accept);
+        const long long g = a.sh.chain_offset + c;
+        involved = pair >= 0 && (g == pair || g == pair + 1);
+    }
+    return __ballot(involved) | (base == 0 ? 1ull : 0ull);
+}
+
 template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 4) * kWave) void pt_round_ob_kernel(const RoundArgs a) {
+__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(4))) void pt_round_ob_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA> e;
     const int c = blockIdx.x;
     e.setup_common(a.d, a.sh, c, lds);
     OB_STAMP_DECL;
+    // bit r % 64: the pipeline restarts at the start of round r (parity 0, the owner's first proposal
+    // from the current point, one barrier more): at the launch's start and where a swap attempt moves
+    // this chain.  Elsewhere a round's first step is a step like any other.
+    u64 restart = 0;
     if (e.is_lik()) {
         e.setup_lik(a.d, a.sh, c);
         if (e.hw < 2)
             e.make_set(e.tick + (u64)e.hw); // the first two ticks' candidates, by waves with nothing else to do yet
         __syncthreads();
         e.cache_rows();
+        int p = 0; // parity of the step about to start
         for (unsigned r = 0; r < a.n_rounds; r++) {
-            __syncthreads();
+            if ((r & 63) == 0)
+                restart = rounds_restarting(e, a, c, r);
+            if ((restart >> (r & 63)) & 1) {
+                p = 0;
+                __syncthreads();
+            }
             for (unsigned s = 0; s < a.n_steps; s++) {
-                const int p = (int)(s & 1);
                 OB_STAMP_BEGIN;
                 e.lik_step(p); // (takes one more barrier inside when a proposal has to be redrawn)
                 OB_STAMP_END;
                 __syncthreads();
+                p ^= 1;
             }
         }
         OB_STAMP_FLUSH;
@@ -430,15 +460,22 @@ __global__ __launch_bounds__((LW + 4) * kWave) void pt_round_ob_kernel(const Rou
         e.setup_lanes(a.sh);
         e.producer_prologue();
         __syncthreads();
+        int p = 0;
         for (unsigned r = 0; r < a.n_rounds; r++) {
-            __syncthreads();
+            if ((r & 63) == 0)
+                restart = rounds_restarting(e, a, c, r);
+            if ((restart >> (r & 63)) & 1) {
+                p = 0;
+                __syncthreads();
+            }
             for (unsigned s = 0; s < a.n_steps; s++) {
                 OB_STAMP_BEGIN;
-                if (e.redraw_pending((int)(s & 1)))
+                if (e.redraw_pending(p))
                     __syncthreads();
                 e.producer_step();
                 OB_STAMP_END;
                 __syncthreads();
+                p ^= 1;
             }
         }
         OB_STAMP_FLUSH;
@@ -460,25 +497,37 @@ __global__ __launch_bounds__((LW + 4) * kWave) void pt_round_ob_kernel(const Rou
         if (a.samples && (e.lane == 63 || (e.cand() && e.qidx == 0)))
             my_sample = a.samples + (size_t)c * (n + 2) + (e.lane == 63 ? n : e.grp);
         const size_t sample_stride = (size_t)a.sh.n_chains * (n + 2);
+        int p = 0;         // parity of the step about to start
+        bool open = false; // a step is in flight whose outcome is not settled yet
         for (unsigned r = 0; r < a.n_rounds; r++) {
-            if (r > 0) // the swap attempt between round r-1 and round r; the other waves wait at the barrier below
-                swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
-            e.owner_first();
-            __syncthreads();
+            if ((r & 63) == 0)
+                restart = rounds_restarting(e, a, c, r);
+            if ((restart >> (r & 63)) & 1) {
+                if (open) { // the last step of the previous round
+                    e.owner_results(p, my_sample);
+                    if (my_sample)
+                        my_sample += sample_stride;
+                    open = false;
+                }
+                if (r > 0) // the swap attempt between round r-1 and round r; the other waves wait at the barrier below
+                    swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
+                p = 0;
+                e.owner_first();
+                __syncthreads();
+            }
             for (unsigned s = 0; s < a.n_steps; s++) {
-                const int p = (int)(s & 1);
                 OB_STAMP_BEGIN;
                 // one batch of LDS reads: the redraw flag, what the prepared proposals settled on
                 // for my parameter, and (owner_results) the partial sums
                 const int pending = *e.s_flag(p);
-                if (s > 0) {
+                if (open) {
                     e.owner_fetch_selected(p);
                     e.owner_results(p, my_sample);
                     if (my_sample)
                         my_sample += sample_stride;
                 }
                 const bool redraw_pending = __builtin_amdgcn_readfirstlane(pending) != 0;
-                e.owner_choose(p, s == 0);
+                e.owner_choose(p, !open);
                 if (redraw_pending) // rare: a proposal in LDS has just been replaced
                     __syncthreads();
                 e.owner_publish(p);
@@ -488,12 +537,14 @@ __global__ __launch_bounds__((LW + 4) * kWave) void pt_round_ob_kernel(const Rou
 #ifdef APEMOST_STAMPS
                 ob_total += __builtin_amdgcn_s_memtime() - ob_t0;
 #endif
+                p ^= 1;
+                open = true;
             }
-            if (a.n_steps > 0) { // the last step of the round
-                e.owner_results((int)(a.n_steps & 1), my_sample);
-                if (my_sample)
-                    my_sample += sample_stride;
-            }
+        }
+        if (open) { // the launch's last step
+            e.owner_results(p, my_sample);
+            if (my_sample)
+                my_sample += sample_stride;
         }
         OB_STAMP_FLUSH;
 #ifdef APEMOST_STAMPS
@@ -1687,7 +1738,7 @@ extern "C" int apemost_hip_launch_round_for(apemost_hip_sampler *s, uint32_t n_s
 // Multi-round launches hand swap records from workgroup to workgroup inside the launch, which
 // is only safe when every workgroup of the grid is resident at once.
 static int max_rounds_per_launch(apemost_hip_sampler *s) {
-    return (s->resident_ok && !s->handoff_failed) ? 64 : 1;
+    return (s->resident_ok && !s->handoff_failed) ? 1024 : 1;
 }
 
 extern "C" int apemost_hip_max_rounds_per_launch(apemost_hip_sampler *s, int32_t *max_rounds) {

@@ -28,11 +28,14 @@ FP64_VALU_PEAK_TF = 78.6  # fp64 vector peak
 # BASELINE.json configs as one GPU sees them: workload, chains per GPU, data points, n_swap
 # (0 = the reference's rule 2000/n_beta of the per-GPU ladder; ladders beyond 2000 chains need an
 # explicit value), burn-in of the device calibration that precedes the timed steps
+# rounds_per_step: rounds of one bench step = of one launch where the ladder is resident (the C host
+# launches up to apemost_hip_max_rounds_per_launch rounds at a time, bounded by its sample buffers):
+# chosen so that a launch is ~1 ms of work and its fixed cost (launch, staging, pipeline start) is small
 CONFIGS = {
-    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000),
-    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000),
-    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000),     # 2048 / 8 GPUs
-    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600),  # 16384 / 8 GPUs
+    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000, rounds_per_step=128),
+    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000, rounds_per_step=32),
+    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000, rounds_per_step=256),  # 2048 / 8 GPUs
+    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600, rounds_per_step=32),  # 16384 / 8 GPUs
 }
 
 
@@ -48,7 +51,7 @@ def parse():
     ap.add_argument("--n-swap", type=int, default=None, help="0 = reference rule 2000/n_beta of the per-GPU ladder")
     ap.add_argument("--burn-in", type=int, default=None, help="BURN_IN_ITERATIONS of the device calibration")
     ap.add_argument("--flags", type=int, default=0, help="apemost_hip_config.flags")
-    ap.add_argument("--rounds-per-step", type=int, default=32)
+    ap.add_argument("--rounds-per-step", type=int, default=None)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--lds", type=int, default=0, help="0 choose, 1 stage the data vector in LDS, 2 read it through L2")
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
