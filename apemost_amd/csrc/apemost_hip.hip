@@ -481,7 +481,10 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
         OB_STAMP_FLUSH;
     } else {
         // the others wait for this wave at every barrier and it has little to issue: let it go first
-        __builtin_amdgcn_s_setprio(3);
+#ifndef APEMOST_OWNER_PRIO
+#define APEMOST_OWNER_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(APEMOST_OWNER_PRIO);
         e.setup_lanes(a.sh);
         e.setup_owner(a.d, a.sh, c);
         chain_load(e, a.d, a.sh, c, a.cur);

@@ -1,0 +1,11 @@
+#!/bin/bash
+set -o pipefail
+out=gpurun_out/r02prio
+mkdir -p $out
+run() { local tag=$1 lib=$2; shift 2
+  APEMOST_HIP_LIB=$lib timeout -k 10 150 python bench.py --cpu-seconds 0 --burn-in 200 "$@" > $out/b_$tag.log 2>&1 || { echo "$tag failed"; tail -5 $out/b_$tag.log; exit 1; }
+  echo "$tag $(tail -n 1 $out/b_$tag.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("%.4g"%d["value"])')"; }
+for rep in 1 2; do for pr in 0 1 3; do
+run c2_prio$pr $PWD/tmp_exp/prio$pr.so --config 2
+run c4_prio$pr $PWD/tmp_exp/prio$pr.so --config 4
+done; done
