@@ -1124,6 +1124,23 @@ static int create_body(apemost_hip_sampler *s) {
         }
         s->resident_ok = s->resident_lds || s->resident_plain;
         s->cooperative = (cfg->flags & APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH) && prop.cooperativeLaunch;
+        if (!s->resident_ok && prop.cooperativeLaunch && s->one_barrier) {
+            // (the one-barrier kernels only: their steps take a microsecond and a launch per round
+            // costs a multiple of that; 2048 one-wave chains of config 5 would fit too, but a round
+            // there is a 340 us launch and the in-launch hand-off was measured 3 % behind)
+            // Between the cautious estimate and the occupancy figure itself (e.g. 257-512 chains of
+            // eight-wave workgroups, two per CU) the runtime decides: multi-round launches go through
+            // hipLaunchCooperativeKernel, which places the whole grid or refuses -- and a refusal
+            // turns this sampler to one round per launch (apemost_hip_run retries, see there).
+            const bool fits_lds = s->lds_data && (long long)cfg->n_chains <= (long long)b_lds * cus;
+            const bool fits_plain = (long long)cfg->n_chains <= (long long)b_plain * cus;
+            if (fits_lds || fits_plain) {
+                s->resident_lds = fits_lds;
+                s->resident_plain = fits_plain;
+                s->resident_ok = true;
+                s->cooperative = true;
+            }
+        }
         // -DADAPT: adapt() sits between a round's steps and its swap attempt and runs as a launch
         // of its own (pt_adapt_kernel), so every round is a launch
         if (cfg->flags & (APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_ADAPT))
@@ -1778,10 +1795,18 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     const bool one_barrier = s->one_barrier && which < 0 && n_steps > 0;
     rc = launch(s, one_barrier ? K_ROUND_OB : K_ROUND, s->cfg.n_chains, &a, stage, s->cooperative && n_rounds > 1);
     if (rc && s->cooperative && n_rounds > 1) {
-        // the runtime cannot place the grid at once: single-round launches from now on
+        // The runtime cannot place the grid at once (nothing has run): this sampler issues one
+        // round per launch from now on, beginning with the rounds asked for here -- the swap
+        // attempt between two of them is then the fused swap-in at the second one's start.
         s->resident_ok = false;
-        return fail(APEMOST_HIP_ERR_INVALID, "cooperative launch of %d workgroups refused (%s); this sampler now allows 1 round per launch",
-                    s->cfg.n_chains, apemost_hip_last_error());
+        const size_t row = (size_t)s->cfg.n_chains * (s->cfg.n_par + 2);
+        for (uint32_t i = 0; i < n_rounds; i++) {
+            rc = launch_round_impl(s, 1, n_steps, i == 0 ? apply_swap : 1, which,
+                                   d_samples ? d_samples + (size_t)i * n_steps * row : nullptr);
+            if (rc)
+                return rc;
+        }
+        return APEMOST_HIP_OK;
     }
     if (rc)
         return rc;
@@ -1814,8 +1839,6 @@ extern "C" int apemost_hip_run(apemost_hip_sampler *s, uint64_t n_rounds, uint32
         const uint64_t k = n_rounds - r < per_launch ? n_rounds - r : per_launch;
         int rc = launch_round_impl(s, (uint32_t)k, n_swap, s->swap_pending, -1,
                                    d_samples ? d_samples + r * n_swap * row : nullptr);
-        if (rc && k > 1 && max_rounds_per_launch(s) == 1)
-            continue; // a refused cooperative launch changed nothing: go on one round at a time
         if (rc)
             return rc;
         r += k;

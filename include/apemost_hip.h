@@ -84,7 +84,9 @@ enum {
      * itself when the grid cannot be co-resident, or after a failed in-launch hand-off) */
     APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES = 1,
     /* multi-round launches go through hipLaunchCooperativeKernel: the runtime guarantees (or
-     * refuses) co-residency of the whole grid instead of the engine's occupancy estimate */
+     * refuses) co-residency of the whole grid instead of the engine's occupancy estimate.  The
+     * engine does so by itself where the grid fits the occupancy figure but not its estimate; a
+     * refused launch is re-issued one round at a time, as are all later ones */
     APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH = 2,
     /* stepping launches of workgroups with 8 likelihood waves use the classic two-phase step
      * (two barriers, the chain's wave alone between them) instead of the one-barrier kernel; same

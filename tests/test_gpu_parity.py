@@ -258,12 +258,14 @@ def test_sharded_driver_on_one_gpu_batches_rounds_and_matches_oracle():
 
 
 @pytest.mark.parametrize("n_chain,n_data,flags", [(32, 128, capi.FLAG_SINGLE_ROUND_LAUNCHES), (4096, 64, 0),
-                                                  (32, 128, capi.FLAG_COOPERATIVE_LAUNCH)])
+                                                  (32, 128, capi.FLAG_COOPERATIVE_LAUNCH), (512, 1024, 0)])
 def test_launch_policies_match_oracle(n_chain, n_data, flags):
-    """The three ways a run is cut into launches give the oracle's chain: (i) one round per launch
+    """The ways a run is cut into launches give the oracle's chain: (i) one round per launch
     forced by flag -- every swap is the fused swap-in at launch start; (ii) the same fallback taken
     by the engine itself because 4096 workgroups cannot be co-resident; (iii) multi-round launches
-    placed by hipLaunchCooperativeKernel."""
+    placed by hipLaunchCooperativeKernel on request; (iv) the same chosen by the engine where the
+    grid fits the occupancy figure but not its cautious estimate (512 workgroups of 8 waves, two per
+    CU)."""
     torch = _torch()
     from apemost_amd.distributed import HipShardEngine, ShardedLadder
     w = wl.simplesin(n_data=n_data, n_chain=n_chain)
@@ -271,7 +273,7 @@ def test_launch_policies_match_oracle(n_chain, n_data, flags):
     st, lad, rng = make_pair(w, n_chain, seed=seed)
     s = HipSampler(w.model, 4, n_chain, w.data, seed=seed, flags=flags)
     s.set_state(st)
-    if flags == capi.FLAG_COOPERATIVE_LAUNCH:
+    if flags == capi.FLAG_COOPERATIVE_LAUNCH or n_chain == 512:
         assert s.max_rounds_per_launch > 1
     else:
         assert s.max_rounds_per_launch == 1
@@ -287,6 +289,8 @@ def test_launch_policies_match_oracle(n_chain, n_data, flags):
     assert_match(dev, lad, rng, what="launch policy")
     np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
     assert dev.swapcount.sum() > (10 if n_chain < 100 else 0)
+    if n_chain == 512:
+        assert s.max_rounds_per_launch > 1     # the runtime did place the grid
     s.close()
 
 
