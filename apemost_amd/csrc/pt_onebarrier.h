@@ -120,6 +120,7 @@ struct ObEngine {
     double par_val;     // the step in flight proposes this value for my parameter
     double sel_a, sel_r; // ... and the next step would, after an accept / after a reject
     double thr;         // S_max of the step in flight
+    double prior_inflight; // prior of the proposal in flight (models with a prior)
     u64 fail_a, fail_r; // parameter groups whose prepared attempts all failed, per variant
     double cand_y, cand_s, next_y, next_s; // candidates of the tick in flight / of the next one
 
@@ -197,7 +198,7 @@ struct ObEngine {
         x_abs_max = sh.x_abs_max;
         fail_a = fail_r = 0;
         cand_y = cand_s = next_y = next_s = 0;
-        par_val = thr = sel_a = sel_r = 0;
+        par_val = thr = sel_a = sel_r = prior_inflight = 0;
         accepted = false;
         n_accepted = 0;
         m.init_scalar();
@@ -485,10 +486,10 @@ struct ObEngine {
     __device__ __forceinline__ void owner_results(int parity, double *sample) {
         const double sum = tree(parity);
         accepted = sum < thr;
-        double prior_new = prior;
-        const double prob_new = m.finish(sum, beta_all, consts, &prior_new);
+        // (the proposal's prior was computed for its threshold, a step ago: not again)
+        const double prob_new = m.finish_known_prior(sum, beta_all, consts, prior_inflight);
         if (Model<kBase>::kHasPrior)
-            prior = prior_new; // not restored on reject (quirk Q7)
+            prior = prior_inflight; // not restored on reject (quirk Q7)
         n_accepted += accepted ? 1u : 0u; // the four counters move together here (all-parameter steps): settled at the end
         if (accepted) {
             if (cand())
@@ -540,6 +541,7 @@ struct ObEngine {
         double prior_new = 0;
         if (Model<kBase>::kHasPrior)
             prior_new = m.prior_only(consts);
+        prior_inflight = prior_new;
         const double lu = read_lane(cand_y, 63);
         thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());
         if (lane == 0) {
