@@ -203,7 +203,13 @@ def main():
     launch_ms = ev_ms.value / max(launches.value, 1)
     steps_per_launch = (a.steps * R * n_swap * n_local) / max(launches.value, 1)
     achieved_gbs = bytes_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9
-    flops_per_step = {"simplesin": 28.0, "sine3": 3 * 24.0 + 4}.get(w.name, 40.0) * w.n_data
+    # fp64 operations per data point as the kernels issue them, an FMA counted as two:
+    # a sine with its argument is 28 (3 + reduction 7 + polynomial 18); simplesin adds 5 around it,
+    # sine3 2 per sine and 4 per point; the pulse models per mode 19 (one division by reciprocal),
+    # plus logarithm and final quotient ~50; pulse_vrot 61 instructions, 38 of them FMAs
+    modes = max(1, (w.n_par - 2) // 2)
+    flops_per_point = {"simplesin": 33.0, "sine3": 3 * 30.0 + 4, "pulse": 19.0 * modes + 50, "pulse_vrot": 99.0}
+    flops_per_step = flops_per_point.get(w.name, 40.0) * w.n_data
     # HBM bytes per launch come from the PMC counters, which cannot be read inside this process:
     # `traffic` stays null in this line; the figure profiled with `rocprofv3 --pmc` on this same
     # command (profiles/README.md) is quoted as `traffic_profiled` when the workload is the one it
