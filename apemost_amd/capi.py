@@ -60,7 +60,7 @@ EXPORTS = [
     "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
     "apemost_hip_samples_read", "apemost_hip_samples_free", "apemost_hip_samples_read_async",
     "apemost_hip_samples_wait", "apemost_hip_host_alloc", "apemost_hip_host_free", "apemost_hip_swap_pair",
-    "apemost_hip_sampler_swap_pair",
+    "apemost_hip_sampler_swap_pair", "apemost_hip_rounds_within_shard",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_edge_exchange", "apemost_hip_run_shards",
     "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_calibrate_begin",
@@ -124,6 +124,8 @@ def lib():
     L.apemost_hip_swap_pair.restype = C.c_int64
     L.apemost_hip_sampler_swap_pair.argtypes = [C.c_void_p, C.c_uint64]
     L.apemost_hip_sampler_swap_pair.restype = C.c_int64
+    L.apemost_hip_rounds_within_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+    L.apemost_hip_rounds_within_shard.restype = C.c_int64
     L.apemost_hip_edge_doubles.argtypes = [C.c_int32]
     L.apemost_hip_edge_doubles.restype = C.c_int32
     L.apemost_hip_edge_export.argtypes = [vp, C.c_int, vp]

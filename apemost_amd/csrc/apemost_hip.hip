@@ -1966,6 +1966,22 @@ extern "C" int64_t apemost_hip_sampler_swap_pair(const apemost_hip_sampler *s, u
     return (int)(nb * 1000 * (out[1] * (1.0 / 4294967296.0))) % (nb - 1);
 }
 
+extern "C" int64_t apemost_hip_rounds_within_shard(const apemost_hip_sampler *s, uint64_t first_round,
+                                                   int64_t max_rounds) {
+    if (!s || max_rounds <= 0)
+        return 0;
+    const int64_t lo = s->cfg.chain_offset, hi = lo + s->cfg.n_chains, n = s->cfg.n_chains_global;
+    if (lo == 0 && hi == n) // the whole ladder: no edge to straddle
+        return max_rounds;
+    int64_t k = 0;
+    for (; k < max_rounds; k++) {
+        const int64_t a = apemost_hip_sampler_swap_pair(s, first_round + (uint64_t)k);
+        if (a >= 0 && (a == lo - 1 || (a == hi - 1 && a + 1 < n)))
+            break;
+    }
+    return k;
+}
+
 extern "C" int32_t apemost_hip_edge_doubles(int32_t n_par) { return 3 + 2 * n_par; }
 
 extern "C" int apemost_hip_edge_export(apemost_hip_sampler *s, int side, double *d_buf) {

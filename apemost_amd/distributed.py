@@ -23,7 +23,7 @@ class ShardedLadder:
                                                       between them, all inside the local shard
          max_rounds_per_launch()
          edge_export(side) -> tensor, edge_import(side, tensor), fence()
-         swap_pair(round) -> a,  comm_stream() context manager
+         swap_pair(round) -> a,  rounds_within_shard(first, max) -> k,  comm_stream() context manager
        `HipShardEngine` below is the product engine; the gloo tests plug in an oracle-backed one."""
 
     def __init__(self, engine, n_global, chain_offset, n_local, rank, world, dist=None):
@@ -86,10 +86,6 @@ class ShardedLadder:
                     req.wait()
                 self.e.fence()   # (priming happens once, before anything is timed: plain fences)
 
-    def _straddles(self, swap_index):
-        a = self.e.swap_pair(swap_index)
-        return a >= 0 and (a == self.lo - 1 or (a == self.hi - 1 and a + 1 < self.n_global))
-
     def launch_rounds(self, n_rounds, n_steps, samples=None):
         """one engine launch: [pending swap] steps [swap] steps ...; the caller guarantees that the
         n_rounds-1 swaps inside the launch stay within this shard"""
@@ -111,9 +107,9 @@ class ShardedLadder:
         r = 0
         while r < n_rounds:
             first_inside = self.round + (1 if self.swap_pending else 0)  # swap index after the launch's 1st round
-            k = 1
-            while k < min(limit, n_rounds - r) and not self._straddles(first_inside + k - 1):
-                k += 1
+            # the launch's first round, plus as many more as have their opening swap attempt inside
+            # the shard (one call: a ctypes call per round would cost more than the round at n_swap 1)
+            k = 1 + self.e.rounds_within_shard(first_inside, min(limit, n_rounds - r) - 1)
             self.launch_rounds(k, n_swap, None if samples is None else samples[r:r + k])
             r += k
         if finalize and self.swap_pending:
@@ -203,6 +199,9 @@ class HipShardEngine:
 
     def swap_pair(self, round_):
         return self.s.swap_pair(round_)
+
+    def rounds_within_shard(self, first_round, max_rounds):
+        return self.s.rounds_within_shard(first_round, max_rounds)
 
     def comm_stream(self):
         # enqueue the NCCL(=RCCL) ops relative to the engine's own stream: no host sync needed

@@ -156,6 +156,10 @@ class HipSampler:
         """lower chain of the pair swap attempt `round_` picks under this sampler's swap schedule"""
         return int(self.L.apemost_hip_sampler_swap_pair(self._h, round_))
 
+    def rounds_within_shard(self, first_round, max_rounds):
+        """how many swap attempts from `first_round` on (at most max_rounds) do not straddle an edge of this shard"""
+        return int(self.L.apemost_hip_rounds_within_shard(self._h, first_round, max_rounds))
+
     @property
     def max_rounds_per_launch(self):
         v = C.c_int32(0)

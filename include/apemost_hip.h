@@ -263,6 +263,10 @@ int64_t apemost_hip_swap_pair(uint64_t seed, uint64_t round, int64_t n_chains_gl
 /* the same for this sampler's ladder and swap schedule (with APEMOST_HIP_FLAG_RANDOMSWAP the pair
  * comes from word 1 of the block) */
 int64_t apemost_hip_sampler_swap_pair(const apemost_hip_sampler *s, uint64_t round);
+/* how many of the swap attempts first_round, first_round + 1, ... (at most max_rounds) pick a pair
+ * that lies inside this sampler's shard or outside it altogether, i.e. stops at the first pair that
+ * straddles one of the shard's edges: the rounds a sharded ladder may put into one launch */
+int64_t apemost_hip_rounds_within_shard(const apemost_hip_sampler *s, uint64_t first_round, int64_t max_rounds);
 
 /* sharded ladders: the swap partner across a shard edge.  side 0 = lower
  * neighbour (chain_offset-1), 1 = upper neighbour.  A record is

@@ -71,6 +71,16 @@ class OracleShardEngine:
         u = orc.philox_stream(self.seed, 2 ** 63, 1, start=4 * round_)[0] / 2 ** 32
         return orc.lib().orc_swap_pair_index(u, self.n_global)
 
+    def rounds_within_shard(self, first_round, max_rounds):
+        lo, hi = self.lad.chain_offset, self.lad.chain_offset + self.lad.n_chain
+        k = 0
+        while k < max_rounds:
+            a = self.swap_pair(first_round + k)
+            if a >= 0 and (a == lo - 1 or (a == hi - 1 and a + 1 < self.n_global)):
+                break
+            k += 1
+        return k
+
     def comm_stream(self):
         return self._null()
 

@@ -294,6 +294,24 @@ def test_launch_policies_match_oracle(n_chain, n_data, flags):
     s.close()
 
 
+def test_rounds_within_shard_stops_at_the_first_straddling_pair():
+    """apemost_hip_rounds_within_shard (what a sharded ladder may put into one launch) against the
+    pairs apemost_hip_sampler_swap_pair predicts one by one"""
+    w = small_workloads()["simplesin"]
+    s = HipSampler(w.model, 4, 4, w.data, seed=5, chain_offset=4, n_chains_global=12)
+    seen = set()
+    for first in (0, 7, 100, 1000):
+        k = s.rounds_within_shard(first, 50)
+        straddle = [s.swap_pair(first + i) in (3, 7) for i in range(50)]
+        assert k == (straddle.index(True) if True in straddle else 50)
+        seen.add(k)
+    assert len(seen) > 1 and s.rounds_within_shard(0, 0) == 0
+    s.close()
+    whole = HipSampler(w.model, 4, 12, w.data, seed=5)
+    assert whole.rounds_within_shard(3, 77) == 77          # no edge to straddle
+    whole.close()
+
+
 def test_impossible_prior_box_is_refused_not_spun_on():
     """min > max can never be hit by the redraw loop (src/markov_chain.c:235-240 would spin on the
     host, a kernel on the GPU): set_state refuses it"""
