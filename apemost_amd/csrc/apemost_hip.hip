@@ -1011,7 +1011,13 @@ static int choose_waves(const apemost_hip_config &c) {
     // chains -- two waves per SIMD with the owner and the producers, no likelihood wave waits for a
     // sibling on its SIMD -- and eight only where a step is long enough to be bound by issue rather
     // than by the chain of dependent operations (>= 8192 points at <= 128 chains).
+    // The pulse likelihood -- a loop over the modes that reads its parameters from LDS as it goes, a
+    // longer chain per point than the others -- is the exception: eight waves up to 256 chains
+    // (256 x 1024: 1.51 vs 1.41e8, 128 x 1024: 9.0 vs 8.2e7; pulse_vrot and sine3 stay with four:
+    // 8.9 vs 8.4e7 and 1.05 vs 1.03e8 at 128 x 1024; tools/gpu_exp_w8.sh).
     int by_chip = (c.n_chains <= 128 && c.n_data >= 8192) ? 8 : c.n_chains <= 512 ? 4 : c.n_chains < 1024 ? 2 : 1;
+    if (c.model == APEMOST_MODEL_PULSE && c.n_chains <= 256)
+        by_chip = 8;
     // never fewer than 2 data points per lane
     int by_data = 1;
     while (by_data < 8 && c.n_data >= by_data * 2 * kWave * 2)
