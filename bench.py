@@ -218,7 +218,7 @@ def main():
     key = "%s/%d/%d/%d/%d/%s" % (w.name, n_local, w.n_data, n_swap, R, "nosamples" if a.no_samples else "samples")
     try:
         for pmc in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
-            if pmc.get("workload_key") == key and world == 1:
+            if pmc.get("workload_key") == key and world == 1 and pmc.get("waves_per_chain", waves) == waves:
                 traffic_profiled = pmc["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError, TypeError):
         pass
