@@ -294,6 +294,25 @@ def test_launch_policies_match_oracle(n_chain, n_data, flags):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["pulse", "pulse_vrot"])
+def test_all_heights_zero_is_nan_as_in_the_reference(name):
+    """y = 0 at every data point: the reference's term is ln 0 + d / 0 = -inf + inf = NaN.  The device
+    logarithm has no zero case of its own in these likelihoods (log_tab_nz): the quotient's
+    reciprocal makes the NaN, in the one-wave kernels (ocml logarithm for pulse) and the others"""
+    w = wl.by_name(name, n_data=300, n_chain=4)
+    p = np.array(w.start, float)
+    if name == "pulse":
+        p[3::2] = 0.0
+    else:
+        p[4] = p[6] = 0.0
+    assert np.isnan(orc.loglike(w.model, p, w.data, 0.7)[0])
+    for waves in (1, 4, 8):
+        s = HipSampler(w.model, w.n_par, 1, w.data, waves_per_chain=waves)
+        prob, _ = s.loglike(p[None, :], np.array([0.7]))
+        assert np.isnan(prob[0]), (name, waves)
+        s.close()
+
+
 def test_rounds_within_shard_stops_at_the_first_straddling_pair():
     """apemost_hip_rounds_within_shard (what a sharded ladder may put into one launch) against the
     pairs apemost_hip_sampler_swap_pair predicts one by one"""
