@@ -15,6 +15,7 @@ ABI_VERSION = 2
 FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH, FLAG_TWO_BARRIER_STEP = 1, 2, 4
 # the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP, -DADAPT)
 FLAG_PROPOSAL_LOGISTIC, FLAG_PROPOSAL_UNIFORM, FLAG_RANDOMSWAP, FLAG_ADAPT = 8, 16, 32, 64
+FLAG_TEST_REFUSE_COOPERATIVE = 128   # test hook (include/apemost_hip.h)
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_CALIBRATION = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)

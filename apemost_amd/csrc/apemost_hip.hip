@@ -1175,7 +1175,8 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
         return fail(APEMOST_HIP_ERR_INVALID, "circular_params names a parameter beyond n_par");
     if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH |
                        APEMOST_HIP_FLAG_TWO_BARRIER_STEP | APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC |
-                       APEMOST_HIP_FLAG_PROPOSAL_UNIFORM | APEMOST_HIP_FLAG_RANDOMSWAP | APEMOST_HIP_FLAG_ADAPT))
+                       APEMOST_HIP_FLAG_PROPOSAL_UNIFORM | APEMOST_HIP_FLAG_RANDOMSWAP | APEMOST_HIP_FLAG_ADAPT |
+                       APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE))
         return fail(APEMOST_HIP_ERR_INVALID, "unknown bits in flags: 0x%x", (unsigned)cfg->flags);
     if ((cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC) && (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM))
         return fail(APEMOST_HIP_ERR_INVALID, "PROPOSAL_LOGISTIC and PROPOSAL_UNIFORM are alternatives");
@@ -1583,6 +1584,8 @@ static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void 
     op.lds = kind == K_ROUND_OB ? ob_lds_bytes(s, op.lds_data) : op.lds_data ? s->lds_bytes : s->lds_fixed_bytes;
     op.st = s->stream;
     op.args = args;
+    if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
+        return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: cooperative launch refused (test hook)");
     const hipError_t err = dispatch(s->kmodel, s->waves, op);
     if (err != hipSuccess)
         return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));

@@ -109,7 +109,11 @@ enum {
     /* -DADAPT: adapt() after the steps of every round of a stepping launch
      * (src/parallel_tempering.c:282-301, 404) nudges the chain's step widths by 0.99 or 1/0.99
      * towards apemost_hip_config.adapt_target */
-    APEMOST_HIP_FLAG_ADAPT = 64
+    APEMOST_HIP_FLAG_ADAPT = 64,
+    /* test hook: every cooperative launch is treated as refused by the runtime, so that the path a
+     * real refusal takes (the launch re-issued round by round, single-round launches from then on)
+     * can be exercised on a machine where the runtime never refuses */
+    APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE = 128
 };
 
 typedef struct {

@@ -258,7 +258,9 @@ def test_sharded_driver_on_one_gpu_batches_rounds_and_matches_oracle():
 
 
 @pytest.mark.parametrize("n_chain,n_data,flags", [(32, 128, capi.FLAG_SINGLE_ROUND_LAUNCHES), (4096, 64, 0),
-                                                  (32, 128, capi.FLAG_COOPERATIVE_LAUNCH), (512, 1024, 0)])
+                                                  (32, 128, capi.FLAG_COOPERATIVE_LAUNCH), (512, 1024, 0),
+                                                  (32, 128, capi.FLAG_COOPERATIVE_LAUNCH | capi.FLAG_TEST_REFUSE_COOPERATIVE),
+                                                  (512, 1024, capi.FLAG_TEST_REFUSE_COOPERATIVE)])
 def test_launch_policies_match_oracle(n_chain, n_data, flags):
     """The ways a run is cut into launches give the oracle's chain: (i) one round per launch
     forced by flag -- every swap is the fused swap-in at launch start; (ii) the same fallback taken
@@ -273,7 +275,8 @@ def test_launch_policies_match_oracle(n_chain, n_data, flags):
     st, lad, rng = make_pair(w, n_chain, seed=seed)
     s = HipSampler(w.model, 4, n_chain, w.data, seed=seed, flags=flags)
     s.set_state(st)
-    if flags == capi.FLAG_COOPERATIVE_LAUNCH or n_chain == 512:
+    refuse = bool(flags & capi.FLAG_TEST_REFUSE_COOPERATIVE)   # (v) a refused cooperative launch: re-issued round by round
+    if (flags & capi.FLAG_COOPERATIVE_LAUNCH) or n_chain == 512:
         assert s.max_rounds_per_launch > 1
     else:
         assert s.max_rounds_per_launch == 1
@@ -289,8 +292,10 @@ def test_launch_policies_match_oracle(n_chain, n_data, flags):
     assert_match(dev, lad, rng, what="launch policy")
     np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
     assert dev.swapcount.sum() > (10 if n_chain < 100 else 0)
-    if n_chain == 512:
+    if n_chain == 512 and not refuse:
         assert s.max_rounds_per_launch > 1     # the runtime did place the grid
+    if refuse:
+        assert s.max_rounds_per_launch == 1    # ... and after a refusal every launch holds one round
     s.close()
 
 
