@@ -1439,16 +1439,12 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
         if (coop) {
             // the runtime places the whole grid at once or refuses the launch
             void *params[] = {const_cast<void *>(args)};
-            if (kCanProduce && producers)
-                return hipLaunchCooperativeKernel((const void *)pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>, g, bp,
-                                                  params, (unsigned int)lds, st);
-            return hipLaunchCooperativeKernel((const void *)pt_round_kernel<MODEL, WAVES, LDS, false>, g, b, params,
-                                              (unsigned int)lds, st);
+            return hipLaunchCooperativeKernel((const void *)pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>, g, bp,
+                                              params, (unsigned int)lds, st);
         }
-        if (kCanProduce && producers)
-            hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
-        else
-            hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, false>), g, b, lds, st, *(const RoundArgs *)args);
+        // (workgroups of four and more waves always carry their producer duty: the variant without
+        // it is not instantiated)
+        hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
         break;
     case K_ROUND_OB:
         if constexpr (has_one_barrier(WAVES)) {
@@ -1471,12 +1467,8 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
         hipLaunchKernelGGL((pt_loglike_kernel<MODEL % kVariantModel, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
         break;
     case K_CALIB:
-        if (kCanProduce && producers)
-            hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st,
-                               *(const CalibArgs *)args);
-        else
-            hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, false>), g, b, lds, st,
-                               *(const CalibArgs *)args);
+        hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st,
+                           *(const CalibArgs *)args);
         break;
     }
     return hipGetLastError();
@@ -1659,10 +1651,6 @@ extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const doub
 template <int MODEL, int WAVES>
 static hipError_t set_lds_attr(size_t bytes) {
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess)
-        return e;
     e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true, has_producer(WAVES)>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess)
@@ -1685,8 +1673,7 @@ static hipError_t set_lds_attr(size_t bytes) {
         if (e != hipSuccess)
             return e;
     }
-    return hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
 }
 
 struct LdsAttrOp {
@@ -1712,11 +1699,8 @@ struct OccupancyOp {
                 return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS>,
                                                                     (WAVES + 4) * kWave, lds_bytes);
         }
-        if (kCanProduce && producers)
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
-                                                                block_threads(WAVES, true), lds_bytes);
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, false>,
-                                                            block_threads(WAVES, false), lds_bytes);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
+                                                            block_threads(WAVES, kCanProduce), lds_bytes);
     }
 };
 
