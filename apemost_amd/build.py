@@ -20,8 +20,9 @@ def _stale(target, sources):
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, "apemost_hip.hip"), os.path.join(CSRC, "pt_device.h"),
-            os.path.join(ROOT, "include", "apemost_hip.h")]
+    srcs = [os.path.join(CSRC, "apemost_hip.hip")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(ROOT, "include", "apemost_hip.h")]   # the one translation unit and everything it includes
     if force or _stale(HIP_LIB, srcs):
         cmd = [HIPCC] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", HIP_LIB,
                                      srcs[0]]
