@@ -93,7 +93,7 @@ def test_calibration_under_a_proposal_law_matches_oracle(law):
         assert_match(dev, lad, rng, what="calibrate %s waves=%d" % (law, waves))
 
 
-@pytest.mark.parametrize("waves,flags", [(8, 0), (1, 0), (4, capi.FLAG_SINGLE_ROUND_LAUNCHES)])
+@pytest.mark.parametrize("waves,flags", [(8, 0), (4, 0), (1, 0), (4, capi.FLAG_SINGLE_ROUND_LAUNCHES)])
 def test_randomswap_schedule_matches_oracle(waves, flags):
     """-DRANDOMSWAP: one more uniform ahead of the pair choice; in-launch swaps and swaps fused into
     the next launch's start read the same shifted words"""
