@@ -1,4 +1,6 @@
 #!/bin/bash
+# A/B script behind a number in DESIGN.md.  The libraries it compares (tmp_exp/*.so, not tracked) are development
+# builds: apemost_amd.build.build_dev(models, waves, out=..., extra=[-D switches]) of the commit that quotes the number.
 set -o pipefail
 out=gpurun_out/r02c3
 mkdir -p $out
