@@ -318,6 +318,43 @@ def test_all_heights_zero_is_nan_as_in_the_reference(name):
         s.close()
 
 
+@pytest.mark.parametrize("n_modes", [1, 2, 3, 4])
+def test_pulse_few_modes_paths_match_oracle(n_modes):
+    """Model<PULSE>::term evaluates one to three modes side by side (few_modes<M>) and more in a loop:
+    log-likelihood and a short run against the oracle for each path, one-wave and one-barrier kernels"""
+    rs = np.random.RandomState(3 + n_modes)
+    nu = np.linspace(10, 12, 300)
+    modes = [(10.3 + 0.4 * k, 3.0 - 0.5 * k) for k in range(n_modes)]
+    y = sum(h / (1 + (2 * np.pi * (f - nu) * 5.0) ** 2) for f, h in modes) + 0.05
+    data = np.stack([nu, y * rs.exponential(1.0, len(nu))], 1)
+
+    class W:
+        pass
+    w = W()
+    w.model, w.n_par, w.data = wl.MODEL_PULSE, 2 + 2 * n_modes, data
+    w.start = np.array([5.0, 0.05] + [v for f, h in modes for v in (f, h)])
+    w.pmin = np.array([0.1, 0] + [v for _ in modes for v in (10, 0)], float)
+    w.pmax = np.array([50, 1] + [v for _ in modes for v in (12, 20)], float)
+    w.step = (w.pmax - w.pmin) * 0.02
+    for waves in (1, 4):
+        s = HipSampler(w.model, w.n_par, 1, w.data, waves_per_chain=waves)
+        pts = w.pmin + (w.pmax - w.pmin) * rs.uniform(0.1, 0.9, (5, w.n_par))
+        prob, prior = s.loglike(pts, np.full(5, 0.8))
+        for k in range(5):
+            ref, ref_prior = orc.loglike(w.model, pts[k], w.data, 0.8)
+            assert abs(prob[k] - ref) <= 1e-12 * abs(ref) and abs(prior[k] - ref_prior) <= 1e-12 * abs(ref_prior)
+        s.close()
+        st, lad, rng = make_pair(w, 4, seed=21)
+        s = HipSampler(w.model, w.n_par, 4, w.data, seed=21, waves_per_chain=waves)
+        s.set_state(st)
+        s.run_sampler(20, 5)
+        s.synchronize()
+        dev = s.get_state()
+        s.close()
+        orc.run_sampler(lad, rng, 20, 5)
+        assert_match(dev, lad, rng, what="pulse %d modes waves %d" % (n_modes, waves))
+
+
 def test_rounds_within_shard_stops_at_the_first_straddling_pair():
     """apemost_hip_rounds_within_shard (what a sharded ladder may put into one launch) against the
     pairs apemost_hip_sampler_swap_pair predicts one by one"""
