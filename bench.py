@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the device calibration before the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
+    ap.add_argument("--calib-dump", default=None, help="write the calibration's per-chain status and sweep counts (JSON)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even with one rank")
     a = ap.parse_args()
     for k, v in CONFIGS[a.config].items():
@@ -98,6 +99,29 @@ def cpu_baseline(w, st_template, n_swap, seconds):
     return {"value": steps / dt, "unit": "Metropolis steps/s", "cores": cores, "kind": "port",
             "sample": "%d rounds x %d steps x %d chains of the same workload in %.1f s (oracle, OpenMP over chains)"
                       % (rounds, n_swap, st_template.n_chain, dt)}
+
+
+def calibration_block(wall_s, status, iters, ccfg, n_par):
+    """What the device calibration before the timed region did (markov_chain_calibrate for every chain
+    of the shard: burn_in + markov_chain_calibrate_orig, src/markov_chain_calibrate.c:1039-1180).
+    A sweep = n_par single-parameter updates; every iter_readjust sweeps are followed by iter_readjust
+    all-parameter updates; burn_in rounds its two halves up to blocks of 200 (src/markov_chain.c:34-79).
+    Every update is one likelihood evaluation."""
+    it = np.asarray(iters, dtype=np.int64)
+    half, full = ccfg.burn_in_iterations // 2, ccfg.burn_in_iterations
+    burn = -(-half // 200) * 200 if half > 0 else 0
+    while burn < full:
+        burn += 200
+    cycles = it // ccfg.iter_readjust
+    evals = burn + it * n_par + cycles * ccfg.iter_readjust
+    q = [int(x) for x in np.percentile(it, [0, 25, 50, 75, 90, 99, 100])]
+    return {"wall_s": wall_s, "chains": int(it.size), "ok": int((np.asarray(status) == 0).sum()),
+            "sweeps_total": int(it.sum()), "evaluations_total": int(evals.sum()),
+            "evaluations_per_s": float(evals.sum() / wall_s),
+            "evaluations_slowest_chain": int(evals.max()),
+            "sweeps_percentiles_0_25_50_75_90_99_100": q,
+            # chains still running as a share of chain-time until the slowest one ends: 1 = no tail
+            "active_share": float(evals.sum() / (evals.max() * it.size))}
 
 
 def main():
@@ -146,13 +170,22 @@ def main():
                    n_chains_global=n_global, waves_per_chain=a.waves, lds_policy=a.lds, flags=a.flags)
     s.set_state(st)
     calibrated = None
+    calibration = None
     if not a.no_calibrate:
         # markov_chain_calibrate (burn-in + step-width calibration towards TARGET_ACCEPTANCE_RATE) for
         # every chain at its own beta, as calibrate_rest leaves a ladder: the timed steps then accept at
         # the rate of a production run instead of the ~0 of guessed step widths
         s.calc_model(0, n_local)
-        status, _ = s.markov_chain_calibrate(0, n_local, capi.calib_defaults(burn_in_iterations=a.burn_in))
+        s.synchronize()
+        ccfg = capi.calib_defaults(burn_in_iterations=a.burn_in)
+        tc = time.perf_counter()
+        status, iters = s.markov_chain_calibrate(0, n_local, ccfg)
+        calib_wall = time.perf_counter() - tc
         calibrated = int((status == 0).sum())
+        calibration = calibration_block(calib_wall, status, iters, ccfg, w.n_par)
+        if a.calib_dump and rank == 0:
+            json.dump({"config": a.config, "burn_in": a.burn_in, "wall_s": calib_wall, "status": status.tolist(),
+                       "sweeps": [int(x) for x in iters]}, open(a.calib_dump, "w"))
     acc0 = s.get_state()
     waves, lds = s.geometry
     samples = None
@@ -247,6 +280,10 @@ def main():
                      "fp64_valu_frac": flops_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e12
                                        / FP64_VALU_PEAK_TF},
     }
+    if calibration is not None:
+        # the calibration's likelihood evaluations per second against the round kernel's on the same ladder
+        calibration["rate_vs_round_kernel"] = calibration["evaluations_per_s"] / (value / world)
+        out["calibration"] = calibration
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, acc0, n_swap, a.cpu_seconds)
