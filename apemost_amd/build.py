@@ -19,16 +19,46 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+OBJ = os.path.join(CSRC, "obj")
+N_MODEL_TUS = 8   # models 0-3 and their variant instantiations 4-7 (pt_device.h kVariantModel)
+
+
+def _sources():
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(ROOT, "include", "apemost_hip.h")]
+    return os.path.join(CSRC, "apemost_hip.hip"), os.path.join(CSRC, "apemost_model.hip"), headers
+
+
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, "apemost_hip.hip")] + sorted(
-        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
-        os.path.join(ROOT, "include", "apemost_hip.h")]   # the one translation unit and everything it includes
-    if force or _stale(HIP_LIB, srcs):
-        cmd = [HIPCC] + HIP_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", HIP_LIB,
-                                     srcs[0]]
+    """libapemost_hip.so from nine translation units compiled side by side: the host side of the C ABI
+    (apemost_hip.hip) and one unit per likelihood model holding all of that model's kernels
+    (apemost_model.hip with -DAPEMOST_TU_MODEL=k).  Only what is older than its sources is rebuilt."""
+    from concurrent.futures import ThreadPoolExecutor
+    abi_src, model_src, headers = _sources()
+    os.makedirs(OBJ, exist_ok=True)
+    compile_flags = [f for f in HIP_FLAGS if f != "-shared"] + ["-c", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    jobs = []
+    abi_obj = os.path.join(OBJ, "abi.o")
+    if force or _stale(abi_obj, [abi_src] + headers):
+        jobs.append([HIPCC] + compile_flags + ["-o", abi_obj, abi_src])
+    objs = [abi_obj]
+    for k in range(N_MODEL_TUS):
+        obj = os.path.join(OBJ, "model_%d.o" % k)
+        objs.append(obj)
+        if force or _stale(obj, [model_src] + headers):
+            jobs.append([HIPCC] + compile_flags + ["-DAPEMOST_TU_MODEL=%d" % k, "-o", obj, model_src])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+
+    if jobs:
+        workers = max(1, min(len(jobs), os.cpu_count() or 1, int(os.environ.get("APEMOST_BUILD_JOBS", "8"))))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(run, jobs))
+    if jobs or force or _stale(HIP_LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
     return HIP_LIB
 
 
@@ -36,7 +66,7 @@ def build_stamps(verbose=False, wave=0):
     """diagnostic twin of the library with in-kernel s_memtime stamps (tools/stamp_profile.py);
     `wave` selects the wave of workgroup 0 whose step segments are timed, -1 = a timeline of all waves"""
     out = os.path.join(HERE, "libapemost_hip_stamps%s.so" % ("" if wave == 0 else "_tl" if wave < 0 else "_w%d" % wave))
-    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_STAMPS", "-DAPEMOST_STAMP_WAVE=%d" % wave, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out,
+    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_SINGLE_TU", "-DAPEMOST_STAMPS", "-DAPEMOST_STAMP_WAVE=%d" % wave, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out,
                                  os.path.join(CSRC, "apemost_hip.hip")]
     if verbose:
         print(" ".join(cmd))
@@ -57,7 +87,7 @@ def build_dev(models, waves, out=None, extra=(), verbose=False):
     out = out or os.path.join(HERE, "libapemost_hip_dev.so")
     mm = sum(1 << m for m in models)
     wm = sum(1 << w for w in waves)
-    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_DEV_MODELS=%d" % mm, "-DAPEMOST_DEV_WAVES=%d" % wm] + list(extra) + [
+    cmd = [HIPCC] + HIP_FLAGS + ["-DAPEMOST_SINGLE_TU", "-DAPEMOST_DEV_MODELS=%d" % mm, "-DAPEMOST_DEV_WAVES=%d" % wm] + list(extra) + [
         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out, os.path.join(CSRC, "apemost_hip.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH, FLAG_TWO_BARRIER_STEP = 1, 2, 4
 # the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP, -DADAPT)
 FLAG_PROPOSAL_LOGISTIC, FLAG_PROPOSAL_UNIFORM, FLAG_RANDOMSWAP, FLAG_ADAPT = 8, 16, 32, 64
@@ -48,7 +48,8 @@ class CalibConfig(C.Structure):
     _fields_ = [("burn_in_iterations", C.c_uint32), ("iter_limit", C.c_uint32),
                 ("iter_readjust", C.c_uint32), ("no_rescaling_limit", C.c_int32),
                 ("rat_limit", C.c_double), ("target_global", C.c_double),
-                ("max_ar_deviation", C.c_double), ("mul", C.c_double), ("adjust_step", C.c_double)]
+                ("max_ar_deviation", C.c_double), ("mul", C.c_double), ("adjust_step", C.c_double),
+                ("progress_chain", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/apemost_hip.h declares
@@ -65,7 +66,8 @@ EXPORTS = [
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_edge_exchange", "apemost_hip_run_shards",
     "apemost_hip_calib_defaults", "apemost_hip_calibrate_chains", "apemost_hip_calibrate_begin",
-    "apemost_hip_calibrate_end", "apemost_hip_rng_raw",
+    "apemost_hip_calibrate_end", "apemost_hip_calibrate_poll", "apemost_hip_calibrate_cancel", "apemost_hip_calibrate_wait_any",
+    "apemost_hip_calibrate_progress", "apemost_hip_calibrate_stats", "apemost_hip_rng_raw",
     "apemost_hip_rng_attempts", "apemost_hip_timer_begin", "apemost_hip_timer_end",
 ]
 
@@ -139,6 +141,11 @@ def lib():
                                                C.POINTER(C.c_int32), _up]
     L.apemost_hip_calibrate_begin.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(CalibConfig), C.c_int]
     L.apemost_hip_calibrate_end.argtypes = [vp, C.POINTER(C.c_int32), _up]
+    L.apemost_hip_calibrate_poll.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.apemost_hip_calibrate_cancel.argtypes = [vp]
+    L.apemost_hip_calibrate_wait_any.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(C.c_int32)]
+    L.apemost_hip_calibrate_progress.argtypes = [vp, _dp, C.c_int32, C.POINTER(C.c_int32)]
+    L.apemost_hip_calibrate_stats.argtypes = [vp, _up, _up, _up]
     L.apemost_hip_rng_raw.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
                                       C.POINTER(C.c_uint32)]
     L.apemost_hip_rng_attempts.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,

@@ -1,797 +1,22 @@
 // apemost_hip.hip -- kernels and C ABI of the gfx950 parallel-tempering engine
 // (declared in include/apemost_hip.h).  Written for MI355X only.
-#include "pt_device.h"
-#include "pt_onebarrier.h"
+#include "pt_kernels.h"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace apemost;
 
 // ===========================================================================
-// kernels
+// kernels that are not templates over the model (the others: pt_kernels.h)
 // ===========================================================================
-
-// LDS carve (doubles): proposed params [2][64], wave partials [2][16], 8 control words
-constexpr int kFixedLdsDoubles = 2 * kWave + 32 + 8;
-
-struct RoundArgs {
-    DevArrays d;
-    ChainShape sh;
-    int cur;          // which half of the double-buffered fields is current
-    int first;        // first local chain (calc_model on a range)
-    int which;        // -1: all-parameter updates; p: update parameter p only (markov_chain_step_for)
-    int apply_swap;   // fuse tempering_interaction() for swap-stream position `round`
-    unsigned n_steps; // Metropolis steps per round
-    unsigned n_rounds; // rounds in this launch; between them the swap attempts are exchanged in-kernel
-    u64 round;
-    double *samples; // [n_steps][n_chains][n_par+2] or nullptr
-};
-
-// candidate sets kept in LDS: 8-slot ring with producer waves, WAVES without
-__host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? waves : 8; }
-// candidate production as a side duty of waves 1-3 (workgroups of at least 4 waves)
-// (they pay when the chip has idle CUs: few chains; with many chains they only take wave slots)
-__host__ __device__ constexpr bool has_producer(int waves) { return waves >= 4; }
-// The one-barrier round kernel (pt_onebarrier.h) exists for 4 and 8 likelihood waves per chain
-// (+ owner + three candidate producers: workgroups of 8 and 12 waves).  Measured on one MI355X
-// (steps/s, one-barrier 4 / one-barrier 8 / two-phase 4; tools/gpu_exp_ob4.sh):
-//   simplesin  128 x  1024 (n_swap 15): 1.85e8 / 1.66e8 / 1.27e8     64 x 1024: 0.99e8 / 0.88e8
-//   simplesin  256 x  1024 (n_swap  7): 3.18e8 / 1.67e8 / 2.37e8     128 x 4096: 9.2e7 / 8.8e7
-//   pulse      256 x  1024 (n_swap  1): 7.84e7 /   -    / 7.81e7     128 x 16384: 2.43e7 / 2.60e7
-//   pulse      256 x  1024 (n_swap  7): 1.19e8 / 0.89e8 / 1.04e8     128 x 65536: 6.7e6 / 7.2e6
-// With 2 it loses to 4 (128 x 1024: 1.48e8): the data vector no longer fits the registers.
-#ifndef APEMOST_OB_WAVES_MASK
-#define APEMOST_OB_WAVES_MASK 0x110
-#endif
-__host__ __device__ constexpr bool has_one_barrier(int waves) { return (APEMOST_OB_WAVES_MASK >> waves) & 1; }
-__host__ __device__ constexpr int block_threads(int waves, bool) { return waves * kWave; }
-
-template <int MODEL, int WAVES, bool LDS_DATA, bool PRODUCER>
-__device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PRODUCER> &e, const DevArrays &d,
-                                             const ChainShape &sh, int c, double *lds) {
-    constexpr int kThreads = WAVES * kWave;
-    // Wave roles.  A workgroup's wavefronts are dealt to the CU's four SIMDs cyclically (wave w and
-    // w+4 share one, tools/hwid_probe.hip): wave 0 owns the chain, waves 1-3 -- the other three
-    // SIMDs -- produce the candidates as a side duty, so the owner's serial code does not share
-    // issue slots with candidate generation.
-    e.lane = threadIdx.x & (kWave - 1);
-    e.wave = threadIdx.x / kWave;
-    e.tid = e.wave * kWave + e.lane;
-    e.n_par = sh.n_par;
-    e.n_data = sh.n_data;
-    e.consts = sh.consts;
-    e.x_abs_max = sh.x_abs_max;
-    e.circular = sh.circular;
-    e.seed = sh.seed;
-    e.g = (u64)(sh.chain_offset + c);
-    e.parity = 0;
-    e.s_par = lds;              // 2*64 doubles
-    e.s_part = lds + 2 * kWave; // 2*16 doubles, then 8 control words
-    e.s_cand = (double2 *)(lds + kFixedLdsDoubles);
-    double *s_data = lds + kFixedLdsDoubles + cand_slots(WAVES) * 2 * kWave;
-    e.setup_lanes();
-    if (threadIdx.x == 0)
-        *e.fail_flag() = 0; // ordered before its first use by the barrier every kernel has after setup
-    if (d.f != nullptr) // a resident chain: its prior box may make the per-step argument check void
-        e.m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
-    if (LDS_DATA) {
-        // stage the data vector once per launch: coalesced HBM/L2 reads, SoA in LDS
-        for (int i = threadIdx.x; i < 2 * sh.n_data; i += kThreads)
-            s_data[i] = d.data[i];
-        e.xs = s_data;
-        e.ys = s_data + sh.n_data;
-    } else {
-        e.xs = d.data;
-        e.ys = d.data + sh.n_data;
-    }
-}
-
-// Load the chain into wave 0's registers from the read half of the state.
-template <class E>
-__device__ __forceinline__ void chain_load(E &e, const DevArrays &d, const ChainShape &sh, int c,
-                                           int cur) {
-    const int row = c + 1, n = sh.n_par;
-    e.beta_all = d.beta()[row];
-    e.cur = e.best = e.stepw = e.lo = e.hi = 0;
-    e.pacc = e.prej = 0;
-    e.prob = d.prob(cur)[row];
-    e.prior = d.prior(cur)[row];
-    e.prob_best = d.prob_best(cur)[row];
-    e.accept = d.accept()[c];
-    e.reject = d.reject()[c];
-    e.tick = d.ticks()[c];
-    if (e.wave == 0 && e.cand()) {
-        const size_t k = (size_t)c * n + e.grp;
-        e.cur = d.params(cur)[(size_t)row * n + e.grp];
-        e.best = d.params_best(cur)[(size_t)row * n + e.grp];
-        e.stepw = d.step()[k];
-        e.lo = d.pmin()[k];
-        e.hi = d.pmax()[k];
-        e.pacc = d.params_accepts()[k];
-        e.prej = d.params_rejects()[k];
-    }
-}
-
-template <class E>
-__device__ __forceinline__ void chain_store(const E &e, const DevArrays &d, const ChainShape &sh,
-                                            int c, int dst, bool store_step) {
-    const int row = c + 1, n = sh.n_par;
-    if (e.wave != 0)
-        return;
-    if (e.cand() && e.qidx == 0) {
-        const size_t k = (size_t)c * n + e.grp;
-        d.params(dst)[(size_t)row * n + e.grp] = e.cur;
-        d.params_best(dst)[(size_t)row * n + e.grp] = e.best;
-        d.params_accepts()[k] = e.pacc;
-        d.params_rejects()[k] = e.prej;
-        if (store_step)
-            d.step()[k] = e.stepw;
-    }
-    if (e.lane == 63) {
-        d.prob(dst)[row] = e.prob;
-        d.prior(dst)[row] = e.prior;
-        d.prob_best(dst)[row] = e.prob_best;
-        d.accept()[c] = e.accept;
-        d.reject()[c] = e.reject;
-        d.ticks()[c] = e.tick;
-    }
-}
-
-// ---- agent-scope accessors for words another workgroup of the same launch writes or reads
-// (cdna_hip_programming.md Guideline 16: global address space, sc1, never plain) ----
-typedef __attribute__((address_space(1))) u64 gu64;
-__device__ __forceinline__ void st_agent(double *p, double v) {
-    __hip_atomic_store((gu64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_agent(u64 *p, u64 v) {
-    __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 ld_agent(const u64 *p) {
-    return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// bounded relaxed poll by one wave on one word; on timeout the launch's timeout word is set and
-// the host reports the failure (results of that launch are void)
-__device__ __forceinline__ bool wait_at_least(const u64 *word, u64 want, u64 *timeout_word) {
-    for (unsigned spins = 0; ld_agent(word) < want; spins++) {
-        __builtin_amdgcn_s_sleep(2);
-        if (spins > 8000000u) {
-            st_agent(timeout_word, 1);
-            return false;
-        }
-    }
-    return true;
-}
-
-// which neighbour's record a chain read at its latest use of each half of the state block, and for
-// which swap index: before the chain overwrites its row in that half it waits for that reader's ack
-struct SwapMemo { // two named slots, not arrays: a run-time subscript would put them in scratch
-    int partner0, partner1;
-    u64 index0, index1;
-    __device__ __forceinline__ int partner(int half) const { return half ? partner1 : partner0; }
-    __device__ __forceinline__ u64 index(int half) const { return half ? index1 : index0; }
-    __device__ __forceinline__ void set(int half, int p, u64 i) {
-        if (half) {
-            partner1 = p;
-            index1 = i;
-        } else {
-            partner0 = p;
-            index0 = i;
-        }
-    }
-};
-
-// tempering_interaction() (src/parallel_tempering_interaction.c:25-42, 87-123, 125-141) as seen
-// by one chain: every workgroup derives the same pair and uniforms from the replicated swap
-// stream; the two workgroups of the pair evaluate the same expression on the same values and
-// agree without negotiating.  Records are read from half `half` of the state block; `shared`
-// selects agent-scope loads (records published inside this launch) over plain ones (records
-// stored by the previous launch).  Returns the partner's local chain index, or -1.
-// the draws of swap attempt `swap_index`: the lower chain of the pair (-1: no attempt) and the
-// uniform of the acceptance test.  Default: parallel_tempering_decide_swap_now (:87-97), words 0
-// and 1.  -DRANDOMSWAP: parallel_tempering_decide_swap_random(chains, n_beta, 1) (:47-64) draws
-// swap_probability first and compares it with 1.0 / n_swap for the n_swap = 1 its caller passes.
-template <bool VARIANTS>
-__device__ __forceinline__ long long swap_draws(const ChainShape &sh, u64 swap_index, double &u_accept) {
-    const uint4 b = philox_block(sh.seed, APEMOST_HIP_SWAP_SUBSEQUENCE, swap_index);
-    const int nb = (int)sh.n_global;
-    double u = u32_to_uniform(b.x);
-    u_accept = u32_to_uniform(b.y);
-    if (VARIANTS && (sh.variant & kVariantRandomSwap)) {
-        if (!(u < 1.0 / 1))
-            return -1;
-        u = u32_to_uniform(b.y);
-        u_accept = u32_to_uniform(b.z);
-    }
-    return (int)(nb * 1000 * u) % (nb - 1);
-}
-
-template <class E>
-__device__ __forceinline__ int swap_apply(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
-                                          u64 swap_index, bool shared) {
-    double u_accept;
-    const long long a = swap_draws<E::kVariants>(sh, swap_index, u_accept);
-    const double lc = log(u_accept);
-    const long long g = sh.chain_offset + c;
-    if (a < 0 || (g != a && g != a + 1))
-        return -1;
-    const int n = sh.n_par;
-    const int row = c + 1;
-    const int row_a = (g == a) ? row : row - 1, row_b = row_a + 1;
-    const int partner = (g == a) ? row_b : row_a;
-    // own values come from registers, the partner's from memory
-    const double p_prob = shared ? ld_agent(d.prob(half) + partner) : d.prob(half)[partner];
-    const double p_best = shared ? ld_agent(d.prob_best(half) + partner) : d.prob_best(half)[partner];
-    const double a_prob = (g == a) ? e.prob : p_prob, b_prob = (g == a) ? p_prob : e.prob;
-    const double a_beta = d.beta()[row_a], b_beta = d.beta()[row_b];
-    const double r = a_beta * b_prob / b_beta + b_beta * a_prob / a_beta - (a_prob + b_prob);
-    if (r > lc) {
-        // parallel_tempering_do_swap: params exchanged, prob is not (quirk Q1)
-        const double a_best = (g == a) ? e.prob_best : p_best, b_best = (g == a) ? p_best : e.prob_best;
-        const bool a_wins = a_best > b_best;
-        const bool take_best = (g == a) != a_wins; // this chain receives the other one's best (quirk Q3)
-        if (e.cand()) {
-            const double *pp = d.params(half) + (size_t)partner * n + e.grp;
-            const double *pb = d.params_best(half) + (size_t)partner * n + e.grp;
-            e.cur = shared ? ld_agent(pp) : *pp;
-            if (take_best)
-                e.best = shared ? ld_agent(pb) : *pb;
-        }
-        if (take_best)
-            e.prob_best = a_wins ? a_best : b_best;
-        if (g == a && e.lane == 0)
-            d.swapcount()[c] += 1; // inc_swapcount(chains[candidate])
-    }
-    return partner - 1;
-}
-
-// a chain's row in half `half` is about to be overwritten: its latest reader must be done
-template <class E>
-__device__ __forceinline__ void wait_for_reader(const DevArrays &d, const ChainShape &sh, const SwapMemo &memo,
-                                                int half) {
-    const int p = memo.partner(half);
-    if (p >= 0 && p < sh.n_chains)
-        wait_at_least(d.acked() + p, memo.index(half) + 1, d.timeout_word());
-}
-
-// swap attempt at the start of a launch: both records were stored by the previous launch (or
-// imported into a halo row by the host)
-template <class E>
-__device__ __forceinline__ void swap_at_launch_start(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
-                                                     u64 swap_index, SwapMemo &memo) {
-    if (sh.n_global <= 1 || e.wave != 0)
-        return;
-    const int partner = swap_apply(e, d, sh, c, half, swap_index, false);
-    if (partner == -1)
-        return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the reads above have landed
-    if (e.lane == 0)
-        st_agent(d.acked() + c, swap_index + 1);
-    memo.set(half, partner, swap_index);
-}
-
-// swap attempt between two rounds of one launch: the two chains of the pair publish their
-// records into half `half`, wait for each other, then decide (Guideline 16: payload and flag
-// are agent-scope sc1 stores drained by the storing wave; the consumer polls the flag relaxed,
-// takes one agent acquire, and reads the payload with agent-scope loads)
-template <class E>
-__device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const ChainShape &sh, int c, int half,
-                                               u64 swap_index, SwapMemo &memo) {
-    if (sh.n_global <= 1 || e.wave != 0)
-        return;
-    double u_accept;
-    const long long a = swap_draws<E::kVariants>(sh, swap_index, u_accept);
-    const long long g = sh.chain_offset + c;
-    if (a < 0 || (g != a && g != a + 1))
-        return;
-    const int partner = (g == a) ? c + 1 : c - 1;
-    if (partner < 0 || partner >= sh.n_chains) {
-        st_agent(d.timeout_word(), 2); // the host must not schedule a shard-straddling pair in-launch
-        return;
-    }
-    const int n = sh.n_par, row = c + 1;
-    wait_for_reader<E>(d, sh, memo, half);
-    if (e.cand() && e.qidx == 0) {
-        st_agent(d.params(half) + (size_t)row * n + e.grp, e.cur);
-        st_agent(d.params_best(half) + (size_t)row * n + e.grp, e.best);
-    }
-    if (e.lane == 63) {
-        st_agent(d.prob(half) + row, e.prob);
-        st_agent(d.prob_best(half) + row, e.prob_best);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every payload store of this wave has left
-    if (e.lane == 0)
-        st_agent(d.published() + c, swap_index + 1);
-    if (!wait_at_least(d.published() + partner, swap_index + 1, d.timeout_word()))
-        return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    swap_apply(e, d, sh, c, half, swap_index, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (e.lane == 0)
-        st_agent(d.acked() + c, swap_index + 1);
-    memo.set(half, partner, swap_index);
-}
-
-template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
-__global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_round_kernel(const RoundArgs a) {
-    extern __shared__ __align__(16) double lds[];
-    Engine<MODEL, WAVES, LDS_DATA, PROD> e;
-    const int c = blockIdx.x;
-    engine_setup(e, a.d, a.sh, c, lds);
-    chain_load(e, a.d, a.sh, c, a.cur);
-    e.pin_uniforms();
-    SwapMemo memo;
-    memo.partner0 = memo.partner1 = -1;
-    memo.index0 = memo.index1 = 0;
-    if (a.apply_swap)
-        swap_at_launch_start(e, a.d, a.sh, c, a.cur, a.round, memo);
-    e.producer_prologue();
-    __syncthreads();
-    e.cache_rows();
-    e.producer_first_fetch();
-#ifdef APEMOST_STAMPS
-    e.stamps_begin();
-#endif
-
-    const int n = a.sh.n_par;
-    // each lane's slot in the sample row of its chain, advanced by one row set per step
-    double *my_sample = nullptr;
-    if (a.samples && e.wave == 0 && (e.lane == 63 || (e.cand() && e.qidx == 0)))
-        my_sample = a.samples + (size_t)c * (n + 2) + (e.lane == 63 ? n : e.grp);
-    const size_t sample_stride = (size_t)a.sh.n_chains * (n + 2);
-    for (unsigned r = 0; r < a.n_rounds; r++) {
-        if (r > 0) // the swap attempt between round r-1 and round r
-            swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
-        for (unsigned s = 0; s < a.n_steps; s++) {
-            e.step(a.which);
-            if (e.wave == 0) {
-                e.check_best();
-                if (my_sample) {
-                    // the row the reference prints per step: params ("%.15e"), prob, prob-prior
-                    if (e.lane == 63) {
-                        my_sample[0] = e.prob;
-                        my_sample[1] = e.prob - e.prior;
-                    } else {
-                        my_sample[0] = e.cur;
-                    }
-                    my_sample += sample_stride;
-                }
-            }
-        }
-    }
-#ifdef APEMOST_STAMPS
-    e.stamps_flush();
-#endif
-    if (e.wave == 0 && e.lane == 0)
-        a.d.n_iter()[c] += (u64)a.n_steps * a.n_rounds; // mcmc_append_current_parameters, src/mcmc_calculate.c:30-33
-    if (e.wave == 0)
-        wait_for_reader<decltype(e)>(a.d, a.sh, memo, a.cur ^ 1);
-    if (e.tid == 0 && *e.fail_flag())
-        st_agent(a.d.timeout_word(), 3);
-    chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
-}
-
-// The same rounds with one barrier per step (pt_onebarrier.h): LW likelihood wavefronts plus an
-// owner and three candidate producers.  All-parameter steps only; launches with steps.
-//
-// Every role runs its own copy of the round/step loops (the registers a role carries from step to
-// step are then live in its loop only); what the copies share is the barrier sequence: one at the
-// start of a round, one per step, and one more in a step whose prepared proposal has to be redrawn
-// (every wave reads the same LDS flag for that).
-// Diagnostic build (-DAPEMOST_STAMPS): per wave of workgroup 0, the cycles between leaving a step's
-// barrier and arriving at the next one (g_stamps[wave]); g_stamps[15] = whole steps of the owner,
-// barrier to barrier.  Tells which role the others wait for.
-#ifdef APEMOST_STAMPS
-#define OB_STAMP_DECL u64 ob_busy = 0, ob_t0 = 0, ob_total = 0, ob_prev = 0
-#define OB_STAMP_BEGIN ob_t0 = __builtin_amdgcn_s_memtime()
-#define OB_STAMP_END ob_busy += __builtin_amdgcn_s_memtime() - ob_t0
-#define OB_STAMP_FLUSH                                                                            \
-    if (blockIdx.x == 0 && e.lane == 0)                                                           \
-    atomicAdd(&g_stamps[e.hw], ob_busy)
-#else
-#define OB_STAMP_DECL
-#define OB_STAMP_BEGIN
-#define OB_STAMP_END
-#define OB_STAMP_FLUSH
-#endif
-
-// The rounds base .. base+63 of this launch whose opening swap attempt involves chain c (bit r - base):
-// lane l draws the pair of round base + l from the replicated swap stream.  A swap attempt touches
-// its two chains only (src/parallel_tempering_interaction.c:99-141): for every other chain the
-// boundary between two rounds is no event at all, and its pipeline of prepared proposals runs
-// through it.  Every wave of the workgroup evaluates this for itself (one Philox block per 64
-// rounds), so that all of them agree on where the extra barriers are.  Bit 0 of the launch's first
-// block is always set: the pipeline starts there.
-template <class E>
-__device__ __forceinline__ u64 rounds_restarting(const E &e, const RoundArgs &a, int c, unsigned base) {
-    bool involved = false;
-    const unsigned r = base + (unsigned)e.lane;
-    if (a.sh.n_global > 1 && r >= 1 && r < a.n_rounds) {
-        double u_accept;
-        const long long pair = swap_draws<E::kVariants>(a.sh, a.round + r - (a.apply_swap ? 0 : 1), u_accept);
-        const long long g = a.sh.chain_offset + c;
-        involved = pair >= 0 && (g == pair || g == pair + 1);
-    }
-    return __ballot(involved) | (base == 0 ? 1ull : 0ull);
-}
-
-template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(4))) void pt_round_ob_kernel(const RoundArgs a) {
-    extern __shared__ __align__(16) double lds[];
-    ObEngine<MODEL, LW, LDS_DATA> e;
-    const int c = blockIdx.x;
-    e.setup_common(a.d, a.sh, c, lds);
-    OB_STAMP_DECL;
-    // bit r % 64: the pipeline restarts at the start of round r (parity 0, the owner's first proposal
-    // from the current point, one barrier more): at the launch's start and where a swap attempt moves
-    // this chain.  Elsewhere a round's first step is a step like any other.
-    u64 restart = 0;
-    if (e.is_lik()) {
-        e.setup_lik(a.d, a.sh, c);
-        if (e.hw < 2)
-            e.make_set(e.tick + (u64)e.hw); // the first two ticks' candidates, by waves with nothing else to do yet
-        __syncthreads();
-        e.cache_rows();
-        int p = 0; // parity of the step about to start
-        for (unsigned r = 0; r < a.n_rounds; r++) {
-            if ((r & 63) == 0)
-                restart = rounds_restarting(e, a, c, r);
-            if ((restart >> (r & 63)) & 1) {
-                p = 0;
-                __syncthreads();
-            }
-            for (unsigned s = 0; s < a.n_steps; s++) {
-                OB_STAMP_BEGIN;
-                e.lik_step(p); // (takes one more barrier inside when a proposal has to be redrawn)
-                OB_STAMP_END;
-                __syncthreads();
-                p ^= 1;
-            }
-        }
-        OB_STAMP_FLUSH;
-    } else if (e.is_producer()) {
-        e.setup_lanes(a.sh);
-        e.producer_prologue();
-        __syncthreads();
-        int p = 0;
-        for (unsigned r = 0; r < a.n_rounds; r++) {
-            if ((r & 63) == 0)
-                restart = rounds_restarting(e, a, c, r);
-            if ((restart >> (r & 63)) & 1) {
-                p = 0;
-                __syncthreads();
-            }
-            for (unsigned s = 0; s < a.n_steps; s++) {
-                OB_STAMP_BEGIN;
-                if (e.redraw_pending(p))
-                    __syncthreads();
-                e.producer_step();
-                OB_STAMP_END;
-                __syncthreads();
-                p ^= 1;
-            }
-        }
-        OB_STAMP_FLUSH;
-    } else {
-        // the others wait for this wave at every barrier and it has little to issue: let it go first
-#ifndef APEMOST_OWNER_PRIO
-#define APEMOST_OWNER_PRIO 3
-#endif
-        __builtin_amdgcn_s_setprio(APEMOST_OWNER_PRIO);
-        e.setup_lanes(a.sh);
-        e.setup_owner(a.d, a.sh, c);
-        chain_load(e, a.d, a.sh, c, a.cur);
-        e.thr_fn.init(e.consts, e.beta_all);
-        SwapMemo memo;
-        memo.partner0 = memo.partner1 = -1;
-        memo.index0 = memo.index1 = 0;
-        if (a.apply_swap)
-            swap_at_launch_start(e, a.d, a.sh, c, a.cur, a.round, memo);
-        __syncthreads();
-        const int n = a.sh.n_par;
-        double *my_sample = nullptr;
-        if (a.samples && (e.lane == 63 || (e.cand() && e.qidx == 0)))
-            my_sample = a.samples + (size_t)c * (n + 2) + (e.lane == 63 ? n : e.grp);
-        const size_t sample_stride = (size_t)a.sh.n_chains * (n + 2);
-        int p = 0;         // parity of the step about to start
-        bool open = false; // a step is in flight whose outcome is not settled yet
-        for (unsigned r = 0; r < a.n_rounds; r++) {
-            if ((r & 63) == 0)
-                restart = rounds_restarting(e, a, c, r);
-            if ((restart >> (r & 63)) & 1) {
-                if (open) { // the last step of the previous round
-                    e.owner_results(p, my_sample);
-                    if (my_sample)
-                        my_sample += sample_stride;
-                    open = false;
-                }
-                if (r > 0) // the swap attempt between round r-1 and round r; the other waves wait at the barrier below
-                    swap_in_launch(e, a.d, a.sh, c, a.cur ^ (int)(r & 1), a.round + r - (a.apply_swap ? 0 : 1), memo);
-                p = 0;
-                e.owner_first();
-                __syncthreads();
-            }
-            for (unsigned s = 0; s < a.n_steps; s++) {
-                OB_STAMP_BEGIN;
-                // one batch of LDS reads: the redraw flag, what the prepared proposals settled on
-                // for my parameter, and (owner_results) the partial sums
-                const int pending = *e.s_flag(p);
-                if (open) {
-                    e.owner_fetch_selected(p);
-                    e.owner_results(p, my_sample);
-                    if (my_sample)
-                        my_sample += sample_stride;
-                }
-                const bool redraw_pending = __builtin_amdgcn_readfirstlane(pending) != 0;
-                e.owner_choose(p, !open);
-                if (redraw_pending) // rare: a proposal in LDS has just been replaced
-                    __syncthreads();
-                e.owner_publish(p);
-                e.tick++;
-                OB_STAMP_END;
-                __syncthreads();
-#ifdef APEMOST_STAMPS
-                ob_total += __builtin_amdgcn_s_memtime() - ob_t0;
-#endif
-                p ^= 1;
-                open = true;
-            }
-        }
-        if (open) { // the launch's last step
-            e.owner_results(p, my_sample);
-            if (my_sample)
-                my_sample += sample_stride;
-        }
-        OB_STAMP_FLUSH;
-#ifdef APEMOST_STAMPS
-        if (blockIdx.x == 0 && e.lane == 0)
-            atomicAdd(&g_stamps[15], ob_total);
-#endif
-        e.owner_settle_counters((u64)a.n_steps * a.n_rounds);
-        if (e.lane == 0)
-            a.d.n_iter()[c] += (u64)a.n_steps * a.n_rounds;
-        wait_for_reader<decltype(e)>(a.d, a.sh, memo, a.cur ^ 1);
-        if (e.lane == 0 && *e.fail_flag())
-            st_agent(a.d.timeout_word(), 3);
-        chain_store(e, a.d, a.sh, c, a.cur ^ 1, false);
-    }
-}
-
-// calc_model() for every resident chain, in place
-template <int MODEL, int WAVES, bool LDS_DATA>
-__global__ __launch_bounds__(WAVES *kWave) void pt_calc_model_kernel(const RoundArgs a) {
-    extern __shared__ __align__(16) double lds[];
-    Engine<MODEL, WAVES, LDS_DATA> e;
-    const int c = a.first + blockIdx.x;
-    engine_setup(e, a.d, a.sh, c, lds);
-    e.m.clear_box(); // caller-supplied parameters may lie outside their prior box
-    chain_load(e, a.d, a.sh, c, a.cur);
-    __syncthreads();
-    e.cache_rows();
-    e.calc_model_current();
-    if (e.wave == 0 && e.lane == 0) {
-        a.d.prob(a.cur)[c + 1] = e.prob;
-        a.d.prior(a.cur)[c + 1] = e.prior;
-    }
-}
-
-// calc_model() at arbitrary points: params [n][n_par], beta [n] -> prob[n], prior[n]
-struct EvalArgs {
-    ChainShape sh;
-    const double *data;
-    const double *params;
-    const double *beta;
-    double *prob;
-    double *prior;
-};
-
-template <int MODEL, int WAVES, bool LDS_DATA>
-__global__ __launch_bounds__(WAVES *kWave) void pt_loglike_kernel(const EvalArgs a) {
-    extern __shared__ __align__(16) double lds[];
-    Engine<MODEL, WAVES, LDS_DATA> e;
-    DevArrays d;
-    d.f = nullptr;
-    d.u = nullptr;
-    d.n = a.sh.n_chains;
-    d.np = a.sh.n_par;
-    d.data = a.data;
-    const int c = blockIdx.x;
-    engine_setup(e, d, a.sh, c, lds);
-    e.beta_all = a.beta[c];
-    e.prior = 0;
-    e.cur = (e.wave == 0 && e.cand()) ? a.params[(size_t)c * a.sh.n_par + e.grp] : 0.0;
-    __syncthreads();
-    e.cache_rows();
-    e.calc_model_current();
-    if (e.wave == 0 && e.lane == 0) {
-        a.prob[c] = e.prob;
-        a.prior[c] = e.prior;
-    }
-}
-
-// ---- calibration: burn_in + markov_chain_calibrate_orig as a per-chain state machine ----
-struct CalibArgs {
-    DevArrays d;
-    ChainShape sh;
-    int cur;
-    int first;        // first local chain
-    int burn_in_only; // -DSKIP_CALIBRATE_ALLCHAINS
-    apemost_hip_calib_config cfg;
-    int *status;      // [count]
-    u64 *iters;       // [count]
-};
-
-template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
-__global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kernel(const CalibArgs a) {
-    extern __shared__ __align__(16) double lds[];
-    // control word decided by wave 0, read by every wave (kept inside the dynamic
-    // region so the carve base stays 16-byte aligned)
-    volatile int &s_ctl = *(volatile int *)(lds + 2 * kWave + 32);
-    Engine<MODEL, WAVES, LDS_DATA, PROD> e;
-    const int c = a.first + blockIdx.x;
-    const int n = a.sh.n_par;
-    engine_setup(e, a.d, a.sh, c, lds);
-    chain_load(e, a.d, a.sh, c, a.cur);
-    e.pin_uniforms();
-    e.producer_prologue();
-    __syncthreads();
-    e.cache_rows();
-    e.producer_first_fetch();
-    const bool w0 = (e.wave == 0);
-    const apemost_hip_calib_config &cfg = a.cfg;
-
-    // ---- burn_in: src/markov_chain.c:34-79 ----
-    const double original_step = e.stepw;
-    e.stepw = (e.hi - e.lo) * 0.1;
-    unsigned long iter = 0;
-    for (; iter < cfg.burn_in_iterations / 2;) {
-        for (int sub = 0; sub < 200; sub++)
-            e.step(-1);
-        iter += 200;
-        if (w0)
-            e.check_best();
-    }
-    if (w0)
-        e.restart_from_best();
-    e.stepw *= 0.5;
-    for (; iter < cfg.burn_in_iterations;) {
-        for (int sub = 0; sub < 200; sub++)
-            e.step(-1);
-        iter += 200;
-        if (w0)
-            e.check_best();
-    }
-    e.stepw = original_step;
-
-    int status = 0;
-    unsigned long sweeps = 0;
-    if (!a.burn_in_only) {
-        // ---- markov_chain_calibrate_orig: src/markov_chain_calibrate.c:1039-1180 ----
-        double rat_limit = pow(cfg.rat_limit, 1.0 / n);
-        int nchecks_without_rescaling = 0;
-        e.stepw *= cfg.adjust_step;
-        e.reset_accept_rejects();
-        while (true) {
-            for (int p = 0; p < n; p++) {
-                e.step(p);
-                if (w0)
-                    e.check_best();
-            }
-            sweeps++;
-            if (sweeps % cfg.iter_readjust != 0)
-                continue;
-            // per-parameter rescaling; lane p decides for parameter p, the wave
-            // combines the decisions in parameter order like the reference's loop
-            int rescaled = 0, fail = 0;
-            if (w0) {
-                int up = 0, clamped = 0, down = 0, too_large = 0;
-                if (e.cand()) {
-                    const double ar = (double)e.pacc / ((double)e.prej + (double)e.pacc);
-                    if (ar > rat_limit + 0.05) {
-                        up = 1;
-                        e.stepw = e.stepw / cfg.mul;
-                        if (e.stepw / (e.hi - e.lo) > 1) {
-                            e.stepw = 1 * (e.hi - e.lo);
-                            clamped = 1;
-                        }
-                        if (e.stepw / (e.hi - e.lo) > 10000)
-                            too_large = 1;
-                    }
-                    if (ar < rat_limit - 0.05) {
-                        down = 1;
-                        e.stepw = e.stepw * cfg.mul;
-                    }
-                }
-                for (int p = 0; p < n; p++) {
-                    const int src = p * e.Q; // first lane of parameter p's group
-                    const int up_p = __shfl(up, src, kWave), cl_p = __shfl(clamped, src, kWave);
-                    const int dn_p = __shfl(down, src, kWave), tl_p = __shfl(too_large, src, kWave);
-                    if (up_p) {
-                        if (rescaled == 0)
-                            rescaled = -1;
-                        if (cl_p && rescaled == -1)
-                            rescaled = 0;
-                        if (tl_p && !fail)
-                            fail = 1;
-                        if (rescaled == -1)
-                            rescaled = 1;
-                    }
-                    if (dn_p)
-                        rescaled = 1;
-                }
-                if (e.tid == 0)
-                    s_ctl = fail;
-            }
-            __syncthreads();
-            fail = s_ctl;
-            __syncthreads();
-            if (fail) {
-                status = 1;
-                break;
-            }
-            if (w0) {
-                if (rescaled == 0)
-                    nchecks_without_rescaling++;
-                e.restart_from_best();
-                e.reset_accept_rejects();
-            }
-            for (unsigned sub = 0; sub < cfg.iter_readjust; sub++) {
-                e.step(-1);
-                if (w0)
-                    e.check_best();
-            }
-            int ctl = 0; // 0 continue, 1 converged, 2 iteration limit
-            if (w0) {
-                const double delta =
-                    (double)e.accept / (double)(e.accept + e.reject) - cfg.target_global;
-                int reached_perfection;
-                if ((delta < 0 ? -delta : delta) < cfg.max_ar_deviation) {
-                    reached_perfection = 1;
-                } else {
-                    reached_perfection = 0;
-                    if (delta < 0)
-                        rat_limit /= 0.99;
-                    else
-                        rat_limit *= 0.99;
-                }
-                if (nchecks_without_rescaling >= cfg.no_rescaling_limit && reached_perfection == 1 &&
-                    rescaled == 0)
-                    ctl = 1;
-                else if (sweeps > cfg.iter_limit)
-                    ctl = 2;
-                if (e.tid == 0)
-                    s_ctl = ctl;
-            }
-            __syncthreads();
-            ctl = s_ctl;
-            __syncthreads();
-            if (ctl == 1)
-                break;
-            if (ctl == 2) {
-                status = 2;
-                break;
-            }
-        }
-        if (status == 0 && w0)
-            e.reset_accept_rejects();
-    }
-    if (e.tid == 0) {
-        a.status[blockIdx.x] = status;
-        a.iters[blockIdx.x] = sweeps;
-        if (*e.fail_flag())
-            st_agent(a.d.timeout_word(), 3);
-    }
-    // calibration leaves the chain in place: same half of the double buffer
-    chain_store(e, a.d, a.sh, c, a.cur, true);
-}
-
 // ---- test hooks ----
 __global__ void rng_raw_kernel(u64 seed, u64 subseq, u64 offset, int n, unsigned int *out) {
     if (threadIdx.x != 0 || blockIdx.x != 0)
@@ -881,6 +106,63 @@ __global__ void edge_import_kernel(DevArrays d, int n_par, int cur, int row, con
 // host side of the C ABI
 // ===========================================================================
 
+// ---- run-time model -> the translation unit that holds its kernels (pt_kernels.h) ----
+#define APEMOST_EXTERN_MODEL(M) extern template hipError_t apemost::model_dispatch<M>(int, const AnyOp &);
+APEMOST_EXTERN_MODEL(0)
+APEMOST_EXTERN_MODEL(1)
+APEMOST_EXTERN_MODEL(2)
+APEMOST_EXTERN_MODEL(3)
+APEMOST_EXTERN_MODEL(4)
+APEMOST_EXTERN_MODEL(5)
+APEMOST_EXTERN_MODEL(6)
+APEMOST_EXTERN_MODEL(7)
+
+static hipError_t dispatch_any(int model, int waves, const AnyOp &op) {
+    switch (model) {
+    case 0:
+        return model_dispatch<0>(waves, op);
+    case 1:
+        return model_dispatch<1>(waves, op);
+    case 2:
+        return model_dispatch<2>(waves, op);
+    case 3:
+        return model_dispatch<3>(waves, op);
+    case 4:
+        return model_dispatch<4>(waves, op);
+    case 5:
+        return model_dispatch<5>(waves, op);
+    case 6:
+        return model_dispatch<6>(waves, op);
+    case 7:
+        return model_dispatch<7>(waves, op);
+    }
+    return hipErrorInvalidDeviceFunction;
+}
+static hipError_t dispatch(int model, int waves, const LaunchOp &f) {
+    AnyOp op;
+    op.what = AnyOp::LAUNCH;
+    op.launch = f;
+    return dispatch_any(model, waves, op);
+}
+static hipError_t dispatch(int model, int waves, const LdsAttrOp &f) {
+    AnyOp op;
+    op.what = AnyOp::LDS_ATTR;
+    op.lds = f;
+    return dispatch_any(model, waves, op);
+}
+static hipError_t dispatch(int model, int waves, const OccupancyOp<true> &f) {
+    AnyOp op;
+    op.what = AnyOp::OCCUPANCY_LDS;
+    op.occ_lds = f;
+    return dispatch_any(model, waves, op);
+}
+static hipError_t dispatch(int model, int waves, const OccupancyOp<false> &f) {
+    AnyOp op;
+    op.what = AnyOp::OCCUPANCY_PLAIN;
+    op.occ_plain = f;
+    return dispatch_any(model, waves, op);
+}
+
 static thread_local std::string g_last_error;
 
 static int fail(int code, const char *fmt, ...) {
@@ -918,10 +200,23 @@ struct apemost_hip_sampler {
     hipEvent_t ev0, ev1;
     u64 launches, launches_at_begin;
     std::vector<void *> allocations;
-    int *d_status;
-    u64 *d_iters;
-    int calib_capacity;
-    int calib_pending; // chains of a calibrate_begin whose results calibrate_end has not collected yet
+    // a calibration in progress (calibrate_begin .. calibrate_end): launched in segments
+    struct {
+        bool open;      // between begin and end
+        bool in_flight; // a segment has been launched and its records not collected yet
+        bool cancelled;
+        int first, count, burn_in_only, capacity, progress_slot, progress_cap;
+        apemost_hip_calib_config cfg;
+        CalibRec *d_rec;
+        double *d_orig, *d_progress;
+        int *d_list;
+        CalibRec *h_rec; // pinned [capacity]
+        int *h_list;     // pinned [capacity]: slots still calibrating
+        int n_active;
+        hipEvent_t ev;
+        u64 segments, launches_by_waves[9];
+    } cal;
+    unsigned big_lds_set; // bit w: the LDS opt-in of the w-wave kernels has been made
     double *edge_out, *edge_in;  // edge records for in-process shard exchanges (created on first use)
     hipEvent_t ev_exported, ev_imported;
     hipStream_t copy_stream; // drains sample rows while the next launch runs (created on first use)
@@ -974,7 +269,7 @@ extern "C" int apemost_hip_device_info(int device, char *name, size_t name_len, 
     return APEMOST_HIP_OK;
 }
 
-static int enable_big_lds(apemost_hip_sampler *s);
+static int enable_big_lds(apemost_hip_sampler *s, int waves);
 template <bool LDS>
 static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks);
 static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data);
@@ -1034,10 +329,20 @@ static void release(apemost_hip_sampler *s) {
         hipStreamSynchronize(s->stream);
     for (void *p : s->allocations)
         hipFree(p);
-    if (s->d_status)
-        hipFree(s->d_status);
-    if (s->d_iters)
-        hipFree(s->d_iters);
+    if (s->cal.d_rec)
+        hipFree(s->cal.d_rec);
+    if (s->cal.d_orig)
+        hipFree(s->cal.d_orig);
+    if (s->cal.d_progress)
+        hipFree(s->cal.d_progress);
+    if (s->cal.d_list)
+        hipFree(s->cal.d_list);
+    if (s->cal.h_rec)
+        hipHostFree(s->cal.h_rec);
+    if (s->cal.h_list)
+        hipHostFree(s->cal.h_list);
+    if (s->cal.ev)
+        hipEventDestroy(s->cal.ev);
     if (s->copy_stream) {
         hipStreamSynchronize(s->copy_stream);
         hipStreamDestroy(s->copy_stream);
@@ -1107,7 +412,7 @@ static int create_body(apemost_hip_sampler *s) {
                                   : 0);
     s->sh.x_abs_max = INFINITY; // until set_data
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if ((rc = enable_big_lds(s)))
+    if ((rc = enable_big_lds(s, s->waves)))
         return rc;
     {
         // Multi-round launches need every workgroup resident at once.  Blocks per CU from the
@@ -1219,10 +524,8 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->swap_pending = 0;
     s->launches = 0;
     s->launches_at_begin = 0;
-    s->d_status = nullptr;
-    s->d_iters = nullptr;
-    s->calib_capacity = 0;
-    s->calib_pending = 0;
+    memset(&s->cal, 0, sizeof s->cal);
+    s->big_lds_set = 0;
     s->stream = nullptr;
     s->ev0 = s->ev1 = nullptr;
     s->copy_stream = nullptr;
@@ -1428,166 +731,42 @@ extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, in
     return APEMOST_HIP_OK;
 }
 
-// ---- launch dispatch over (model, waves, lds) ----
-enum KernelKind { K_ROUND, K_ROUND_OB, K_CALC, K_EVAL, K_CALIB };
-
-template <int MODEL, int WAVES, bool LDS>
-static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int grid, size_t lds, hipStream_t st,
-                             const void *args) {
-    const dim3 g(grid), b(WAVES * kWave);
-    constexpr bool kCanProduce = has_producer(WAVES);
-    const dim3 bp(block_threads(WAVES, kCanProduce)); // + producer waves
-    switch (kind) {
-    case K_ROUND:
-        if (coop) {
-            // the runtime places the whole grid at once or refuses the launch
-            void *params[] = {const_cast<void *>(args)};
-            return hipLaunchCooperativeKernel((const void *)pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>, g, bp,
-                                              params, (unsigned int)lds, st);
-        }
-        // (workgroups of four and more waves always carry their producer duty: the variant without
-        // it is not instantiated)
-        hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
-        break;
-    case K_ROUND_OB:
-        if constexpr (has_one_barrier(WAVES)) {
-            const dim3 bo((WAVES + 4) * kWave); // + owner + three candidate producers
-            if (coop) {
-                void *params[] = {const_cast<void *>(args)};
-                return hipLaunchCooperativeKernel((const void *)pt_round_ob_kernel<MODEL, WAVES, LDS>, g, bo, params,
-                                                  (unsigned int)lds, st);
-            }
-            hipLaunchKernelGGL((pt_round_ob_kernel<MODEL, WAVES, LDS>), g, bo, lds, st, *(const RoundArgs *)args);
-        } else {
-            return hipErrorInvalidDeviceFunction;
-        }
-        break;
-    case K_CALC:
-        hipLaunchKernelGGL((pt_calc_model_kernel<MODEL % kVariantModel, WAVES, LDS>), g, b, lds, st,
-                           *(const RoundArgs *)args);
-        break;
-    case K_EVAL:
-        hipLaunchKernelGGL((pt_loglike_kernel<MODEL % kVariantModel, WAVES, LDS>), g, b, lds, st, *(const EvalArgs *)args);
-        break;
-    case K_CALIB:
-        hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st,
-                           *(const CalibArgs *)args);
-        break;
-    }
-    return hipGetLastError();
-}
-
-// ---- run-time (model, waves) -> compile-time instantiation ----
-// A development build can restrict what is instantiated (a full build compiles 4 models x 5
-// workgroup shapes x every kernel and takes minutes): -DAPEMOST_DEV_MODELS=<bit per model>
-// -DAPEMOST_DEV_WAVES=<bit per wave count>.  The product build has every bit set.
-#ifndef APEMOST_DEV_MODELS
-#define APEMOST_DEV_MODELS 0xF
-#endif
-#ifndef APEMOST_DEV_WAVES
-#define APEMOST_DEV_WAVES 0x156 // 1, 2, 4, 6, 8
-#endif
-// the variant instantiations (MODEL + kVariantModel: non-default proposal law / swap schedule) exist
-// for the workgroup shapes the engine chooses by itself: 1, 2, 4, 8 waves (build time)
-#ifndef APEMOST_DEV_VARIANTS
-#define APEMOST_DEV_VARIANTS 0x116
-#endif
-constexpr bool built(int model, int waves) {
-    return ((APEMOST_DEV_MODELS >> (model % kVariantModel)) & 1) && ((APEMOST_DEV_WAVES >> waves) & 1) &&
-           (model < kVariantModel || ((APEMOST_DEV_VARIANTS >> waves) & 1));
-}
-
-// f.template run<MODEL, WAVES>() for the sampler's model and workgroup shape
-template <int MODEL, class F>
-static hipError_t dispatch_w(int waves, const F &f) {
-    switch (waves) {
-    case 1:
-        if constexpr (built(MODEL, 1))
-            return f.template run<MODEL, 1>();
-        break;
-    case 2:
-        if constexpr (built(MODEL, 2))
-            return f.template run<MODEL, 2>();
-        break;
-    case 4:
-        if constexpr (built(MODEL, 4))
-            return f.template run<MODEL, 4>();
-        break;
-    case 6:
-        if constexpr (built(MODEL, 6))
-            return f.template run<MODEL, 6>();
-        break;
-    case 8:
-        if constexpr (built(MODEL, 8))
-            return f.template run<MODEL, 8>();
-        break;
-    }
-    return hipErrorInvalidDeviceFunction; // not part of this (development) build
-}
-
-template <class F>
-static hipError_t dispatch(int model, int waves, const F &f) {
-    switch (model) {
-    case APEMOST_MODEL_SIMPLESIN:
-        return dispatch_w<APEMOST_MODEL_SIMPLESIN>(waves, f);
-    case APEMOST_MODEL_PULSE:
-        return dispatch_w<APEMOST_MODEL_PULSE>(waves, f);
-    case APEMOST_MODEL_PULSE_VROT:
-        return dispatch_w<APEMOST_MODEL_PULSE_VROT>(waves, f);
-    case APEMOST_MODEL_SINE3:
-        return dispatch_w<APEMOST_MODEL_SINE3>(waves, f);
-    case kVariantModel + APEMOST_MODEL_SIMPLESIN:
-        return dispatch_w<kVariantModel + APEMOST_MODEL_SIMPLESIN>(waves, f);
-    case kVariantModel + APEMOST_MODEL_PULSE:
-        return dispatch_w<kVariantModel + APEMOST_MODEL_PULSE>(waves, f);
-    case kVariantModel + APEMOST_MODEL_PULSE_VROT:
-        return dispatch_w<kVariantModel + APEMOST_MODEL_PULSE_VROT>(waves, f);
-    case kVariantModel + APEMOST_MODEL_SINE3:
-        return dispatch_w<kVariantModel + APEMOST_MODEL_SINE3>(waves, f);
-    }
-    return hipErrorInvalidDeviceFunction;
-}
-
-struct LaunchOp {
-    KernelKind kind;
-    bool lds_data, producers, coop;
-    int grid;
-    size_t lds;
-    hipStream_t st;
-    const void *args;
-    template <int MODEL, int WAVES>
-    hipError_t run() const {
-        return lds_data ? launch_one<MODEL, WAVES, true>(kind, producers, coop, grid, lds, st, args)
-                        : launch_one<MODEL, WAVES, false>(kind, producers, coop, grid, lds, st, args);
-    }
-};
-
 static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data) {
     return (size_t)kObFixedDoubles * sizeof(double) + (lds_data ? (size_t)2 * s->cfg.n_data * sizeof(double) : 0);
+}
+// dynamic LDS of the two-phase kernels for workgroups of `waves` likelihood wavefronts
+static size_t classic_lds_bytes(const apemost_hip_sampler *s, int waves, bool lds_data) {
+    return (kFixedLdsDoubles + (size_t)cand_slots(waves) * 2 * kWave) * sizeof(double) +
+           (lds_data ? (size_t)2 * s->cfg.n_data * sizeof(double) : 0);
+}
+
+// one launch with an explicit workgroup shape (the stepping launches use the sampler's own; the
+// calibration picks one per segment, by the number of chains that are still calibrating)
+static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, int waves, bool lds_data,
+                        bool coop) {
+    LaunchOp op;
+    op.kind = kind;
+    op.lds_data = lds_data;
+    op.producers = has_producer(waves);
+    op.coop = coop;
+    op.grid = grid;
+    op.lds = (kind == K_ROUND_OB || kind == K_CALIB_OB) ? ob_lds_bytes(s, lds_data) : classic_lds_bytes(s, waves, lds_data);
+    op.st = s->stream;
+    op.args = args;
+    if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
+        return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: cooperative launch refused (test hook)");
+    const hipError_t err = dispatch(s->kmodel, waves, op);
+    if (err != hipSuccess)
+        return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));
+    return APEMOST_HIP_OK;
 }
 
 // stage_data: a launch that walks the data vector only a few times (n_swap < 4, single
 // likelihood evaluations) reads it through L2 instead of copying it into LDS first
 static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true,
                   bool coop = false) {
-    LaunchOp op;
-    op.kind = kind;
-    op.lds_data = s->lds_data && stage_data;
-    op.producers = s->producers;
-    op.coop = coop;
-    op.grid = grid;
-    op.lds = kind == K_ROUND_OB ? ob_lds_bytes(s, op.lds_data) : op.lds_data ? s->lds_bytes : s->lds_fixed_bytes;
-    op.st = s->stream;
-    op.args = args;
-    if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
-        return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: cooperative launch refused (test hook)");
-    const hipError_t err = dispatch(s->kmodel, s->waves, op);
-    if (err != hipSuccess)
-        return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));
-    return APEMOST_HIP_OK;
+    return launch_shape(s, kind, grid, args, s->waves, s->lds_data && stage_data, coop);
 }
-
-static int enable_big_lds(apemost_hip_sampler *s);
 
 extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int32_t count) {
     CHECK_S(s);
@@ -1650,63 +829,6 @@ extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const doub
     return rc;
 }
 
-// kernels that stage > 64 KiB of data in LDS must opt in once per function
-template <int MODEL, int WAVES>
-static hipError_t set_lds_attr(size_t bytes) {
-    hipError_t e;
-    e = hipFuncSetAttribute((const void *)pt_round_kernel<MODEL, WAVES, true, has_producer(WAVES)>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess)
-        return e;
-    e = hipFuncSetAttribute((const void *)pt_calibrate_kernel<MODEL, WAVES, true, has_producer(WAVES)>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess)
-        return e;
-    e = hipFuncSetAttribute((const void *)pt_calc_model_kernel<MODEL % kVariantModel, WAVES, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess)
-        return e;
-    e = hipFuncSetAttribute((const void *)pt_loglike_kernel<MODEL % kVariantModel, WAVES, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess)
-        return e;
-    if constexpr (has_one_barrier(WAVES)) {
-        e = hipFuncSetAttribute((const void *)pt_round_ob_kernel<MODEL, WAVES, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes + 2048);
-        if (e != hipSuccess)
-            return e;
-    }
-    return hipSuccess;
-}
-
-struct LdsAttrOp {
-    size_t bytes;
-    template <int MODEL, int WAVES>
-    hipError_t run() const {
-        return set_lds_attr<MODEL, WAVES>(bytes);
-    }
-};
-
-// blocks of the round kernel one CU admits (occupancy API: registers, LDS, wave slots)
-template <bool LDS>
-struct OccupancyOp {
-    bool producers;
-    bool one_barrier;
-    size_t lds_bytes;
-    int *blocks;
-    template <int MODEL, int WAVES>
-    hipError_t run() const {
-        constexpr bool kCanProduce = has_producer(WAVES);
-        if constexpr (has_one_barrier(WAVES)) {
-            if (one_barrier)
-                return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS>,
-                                                                    (WAVES + 4) * kWave, lds_bytes);
-        }
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
-                                                            block_threads(WAVES, kCanProduce), lds_bytes);
-    }
-};
-
 template <bool LDS>
 static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks) {
     OccupancyOp<LDS> op;
@@ -1717,15 +839,22 @@ static hipError_t round_occupancy(int model, int waves, bool producers, bool one
     return dispatch(model, waves, op);
 }
 
-static int enable_big_lds(apemost_hip_sampler *s) {
-    if (!s->lds_data || s->lds_bytes <= 64 * 1024)
+// Kernels that stage more than 64 KiB must opt in once per function: every kernel of the `waves`-wave
+// shape that may stage the data vector, each with its own footprint (the one-barrier kernels carve
+// 1 KiB more than the two-phase ones).  Made once per shape, before its first launch.
+static int enable_big_lds(apemost_hip_sampler *s, int waves) {
+    if ((s->big_lds_set >> waves) & 1)
         return APEMOST_HIP_OK;
     LdsAttrOp op;
-    op.bytes = s->lds_bytes;
-    const hipError_t e = dispatch(s->kmodel, s->waves, op);
-    if (e != hipSuccess)
-        return fail(APEMOST_HIP_ERR_RUNTIME, "hipFuncSetAttribute(LDS %zu B): %s", s->lds_bytes,
-                    hipGetErrorString(e));
+    op.bytes = classic_lds_bytes(s, waves, true);
+    op.ob_bytes = ob_lds_bytes(s, true);
+    const size_t most = has_one_barrier(waves) && op.ob_bytes > op.bytes ? op.ob_bytes : op.bytes;
+    if (s->cfg.lds_policy != 2 && most > 64 * 1024 && most <= 160 * 1024 - 1024) {
+        const hipError_t e = dispatch(s->kmodel, waves, op);
+        if (e != hipSuccess)
+            return fail(APEMOST_HIP_ERR_RUNTIME, "hipFuncSetAttribute(LDS %zu B): %s", most, hipGetErrorString(e));
+    }
+    s->big_lds_set |= 1u << waves;
     return APEMOST_HIP_OK;
 }
 
@@ -2120,9 +1249,97 @@ extern "C" void apemost_hip_calib_defaults(apemost_hip_calib_config *c) {
     c->max_ar_deviation = 0.01;
     c->mul = 0.85;
     c->adjust_step = 0.5;
+    c->progress_chain = -1;
+    c->reserved = 0;
 }
 
-// markov_chain_calibrate for chains [first, first+count): the launch ...
+// ---- markov_chain_calibrate on the device, in segments -------------------------------------
+// workgroup shape of a segment: what the sampler itself would choose for a ladder of as many chains
+// as are still calibrating (a forced waves_per_chain stays forced)
+struct CalibShape {
+    int waves;
+    bool lds_data, one_barrier;
+    u64 budget;
+};
+
+static CalibShape calib_shape(const apemost_hip_sampler *s, int n_active) {
+    CalibShape g;
+    apemost_hip_config c = s->cfg;
+    c.n_chains = n_active;
+    g.waves = choose_waves(c);
+    if (!built(s->kmodel, g.waves))
+        g.waves = s->waves; // (development builds hold only some shapes)
+    g.one_barrier = has_one_barrier(g.waves) && s->kmodel < kVariantModel && !(s->cfg.flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
+    const size_t bytes = g.one_barrier ? ob_lds_bytes(s, true) : classic_lds_bytes(s, g.waves, true);
+    g.lds_data = bytes <= 160 * 1024 - 1024 && c.lds_policy != 2 && (c.lds_policy == 1 || choose_lds(c, bytes));
+    // A segment of about a quarter of a second: likelihood evaluations a chain gets through in that
+    // time, from a coarse model of one evaluation (1.7 ns per data point and wavefront, 0.7 us at
+    // least, stretched when the wavefronts outnumber the SIMDs).  Always whole blocks, at least one.
+    const double waves_per_wg = g.one_barrier ? g.waves + 4 : g.waves;
+    double t_eval = 1.7e-9 * s->cfg.n_data / g.waves;
+    if (t_eval < 0.7e-6)
+        t_eval = 0.7e-6;
+    const double crowd = n_active * waves_per_wg / 1024.0;
+    if (crowd > 1)
+        t_eval *= crowd;
+    g.budget = (u64)(0.25 / t_eval);
+    if (g.budget < 1)
+        g.budget = 1;
+    // (tests cut the calibration into many more segments: APEMOST_CALIB_SEGMENT_EVALS=1 ends every
+    // launch after one block)
+    if (const char *env = getenv("APEMOST_CALIB_SEGMENT_EVALS")) {
+        const long long v = atoll(env);
+        if (v > 0)
+            g.budget = (u64)v;
+    }
+    return g;
+}
+
+static int calib_launch_segment(apemost_hip_sampler *s) {
+    auto &k = s->cal;
+    const CalibShape g = calib_shape(s, k.n_active);
+    int rc = enable_big_lds(s, g.waves);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(k.d_list, k.h_list, (size_t)k.n_active * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    CalibArgs a;
+    a.d = s->d;
+    a.sh = s->sh;
+    a.cur = s->cur;
+    a.first = k.first;
+    a.burn_in_only = k.burn_in_only;
+    a.progress_slot = k.progress_slot;
+    a.cfg = k.cfg;
+    a.list = k.d_list;
+    a.rec = k.d_rec;
+    a.orig_step = k.d_orig;
+    a.progress = k.d_progress;
+    a.progress_cap = k.progress_cap;
+    a.budget = g.budget;
+    rc = launch_shape(s, g.one_barrier ? K_CALIB_OB : K_CALIB, k.n_active, &a, g.waves, g.lds_data, false);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(k.h_rec, k.d_rec, (size_t)k.count * sizeof(CalibRec), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(k.ev, s->stream));
+    k.in_flight = true;
+    k.segments++;
+    k.launches_by_waves[g.waves]++;
+    return APEMOST_HIP_OK;
+}
+
+// the records of the segment that has just ended: who is still calibrating
+static void calib_collect(apemost_hip_sampler *s) {
+    auto &k = s->cal;
+    int n = 0;
+    for (int i = 0; i < k.n_active; i++) {
+        const int slot = k.h_list[i];
+        if (k.h_rec[slot].stage != CAL_DONE)
+            k.h_list[n++] = slot;
+    }
+    k.n_active = n;
+    k.in_flight = false;
+}
+
 extern "C" int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first, int32_t count,
                                            const apemost_hip_calib_config *c, int burn_in_only) {
     CHECK_S(s);
@@ -2131,63 +1348,164 @@ extern "C" int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first
                     first + count, s->cfg.n_chains);
     if (c->iter_readjust == 0)
         return fail(APEMOST_HIP_ERR_INVALID, "iter_readjust must be > 0");
-    if (s->calib_pending)
+    if (c->progress_chain >= 0 && (c->progress_chain < first || c->progress_chain >= first + count))
+        return fail(APEMOST_HIP_ERR_INVALID, "progress_chain %d outside the chains [%d,%d) of this calibration",
+                    c->progress_chain, first, first + count);
+    auto &k = s->cal;
+    if (k.open)
         return fail(APEMOST_HIP_ERR_INVALID, "calibrate_begin: the previous calibration was not collected (calibrate_end)");
-    if (count > s->calib_capacity) {
-        if (s->d_status)
-            hipFree(s->d_status);
-        if (s->d_iters)
-            hipFree(s->d_iters);
-        s->d_status = nullptr;
-        s->d_iters = nullptr;
-        s->calib_capacity = 0;
-        HIP_TRY(hipMalloc((void **)&s->d_status, count * sizeof(int)));
-        HIP_TRY(hipMalloc((void **)&s->d_iters, count * sizeof(u64)));
-        s->calib_capacity = count;
+    const int cap = (int)(c->iter_limit / c->iter_readjust) + 2; // readjustments a chain can reach
+    if (count > k.capacity || cap > k.progress_cap) {
+        if (k.d_rec)
+            hipFree(k.d_rec);
+        if (k.d_orig)
+            hipFree(k.d_orig);
+        if (k.d_list)
+            hipFree(k.d_list);
+        if (k.d_progress)
+            hipFree(k.d_progress);
+        if (k.h_rec)
+            hipHostFree(k.h_rec);
+        if (k.h_list)
+            hipHostFree(k.h_list);
+        k.d_rec = nullptr, k.d_orig = nullptr, k.d_list = nullptr, k.d_progress = nullptr, k.h_rec = nullptr, k.h_list = nullptr;
+        k.capacity = k.progress_cap = 0;
+        const int want = count > k.capacity ? count : k.capacity, pcap = cap > k.progress_cap ? cap : k.progress_cap;
+        HIP_TRY(hipMalloc((void **)&k.d_rec, (size_t)want * sizeof(CalibRec)));
+        HIP_TRY(hipMalloc((void **)&k.d_orig, (size_t)want * s->cfg.n_par * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&k.d_list, (size_t)want * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&k.d_progress, (size_t)pcap * (1 + 2 * s->cfg.n_par) * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void **)&k.h_rec, (size_t)want * sizeof(CalibRec), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&k.h_list, (size_t)want * sizeof(int), hipHostMallocDefault));
+        k.capacity = want;
+        k.progress_cap = pcap;
     }
-    CalibArgs a;
-    a.d = s->d;
-    a.sh = s->sh;
-    a.cur = s->cur;
-    a.first = first;
-    a.burn_in_only = burn_in_only ? 1 : 0;
-    a.cfg = *c;
-    a.status = s->d_status;
-    a.iters = s->d_iters;
-    const int rc = launch(s, K_CALIB, count, &a);
+    if (!k.ev)
+        HIP_TRY(hipEventCreateWithFlags(&k.ev, hipEventDisableTiming));
+    k.first = first;
+    k.count = count;
+    k.burn_in_only = burn_in_only ? 1 : 0;
+    k.cfg = *c;
+    k.progress_slot = c->progress_chain >= 0 ? c->progress_chain - first : -1;
+    k.cancelled = false;
+    k.segments = 0;
+    memset(k.launches_by_waves, 0, sizeof k.launches_by_waves);
+    HIP_TRY(hipMemsetAsync(k.d_rec, 0, (size_t)count * sizeof(CalibRec), s->stream)); // stage = CAL_INIT
+    HIP_TRY(hipMemsetAsync(k.d_orig, 0, (size_t)count * s->cfg.n_par * sizeof(double), s->stream));
+    for (int i = 0; i < count; i++)
+        k.h_list[i] = i;
+    k.n_active = count;
+    const int rc = calib_launch_segment(s);
     if (rc)
         return rc;
-    s->calib_pending = count;
+    k.open = true;
+    return APEMOST_HIP_OK;
+}
+
+// One turn of the segment loop without blocking: if the segment in flight has ended, its records are
+// collected and the chains that are not done yet are launched again.  *active = chains still
+// calibrating (0: calibrate_end will not wait).
+extern "C" int apemost_hip_calibrate_poll(apemost_hip_sampler *s, int32_t *active) {
+    CHECK_S(s);
+    auto &k = s->cal;
+    if (!k.open)
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_poll without calibrate_begin");
+    if (k.in_flight) {
+        const hipError_t q = hipEventQuery(k.ev);
+        if (q == hipErrorNotReady) {
+            if (active)
+                *active = k.n_active;
+            return APEMOST_HIP_OK;
+        }
+        HIP_TRY(q);
+        calib_collect(s);
+        if (k.n_active > 0 && !k.cancelled) {
+            const int rc = calib_launch_segment(s);
+            if (rc)
+                return rc;
+        }
+    }
+    if (active)
+        *active = k.in_flight ? k.n_active : 0;
+    return APEMOST_HIP_OK;
+}
+
+// for hosts that calibrate on several devices from one thread: returns when a segment of one of the
+// samplers has ended (and its successor has been launched), or when none of them has chains left
+extern "C" int apemost_hip_calibrate_wait_any(apemost_hip_sampler **ss, int32_t n, int32_t *active_total) {
+    if (!ss || n < 1)
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_wait_any: no samplers");
+    for (;;) {
+        int total = 0;
+        bool advanced = false;
+        for (int i = 0; i < n; i++) {
+            if (!ss[i] || !ss[i]->cal.open)
+                continue;
+            const u64 before = ss[i]->cal.segments;
+            const bool was_busy = ss[i]->cal.in_flight;
+            int32_t active = 0;
+            const int rc = apemost_hip_calibrate_poll(ss[i], &active);
+            if (rc)
+                return rc;
+            total += active;
+            advanced = advanced || ss[i]->cal.segments != before || (was_busy && !ss[i]->cal.in_flight);
+        }
+        if (advanced || total == 0) {
+            if (active_total)
+                *active_total = total;
+            return APEMOST_HIP_OK;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// stop after the segment in flight: calibrate_end then returns the chains as they are (status -1 for
+// those that were not done)
+extern "C" int apemost_hip_calibrate_cancel(apemost_hip_sampler *s) {
+    CHECK_S(s);
+    if (!s->cal.open)
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_cancel without calibrate_begin");
+    s->cal.cancelled = true;
     return APEMOST_HIP_OK;
 }
 
 // ... and its results: status[count] / iters[count] of the chains of the matching begin
 extern "C" int apemost_hip_calibrate_end(apemost_hip_sampler *s, int32_t *status, uint64_t *iters) {
     CHECK_S(s);
-    const int count = s->calib_pending;
-    if (count <= 0)
+    auto &k = s->cal;
+    if (!k.open)
         return fail(APEMOST_HIP_ERR_INVALID, "calibrate_end without calibrate_begin");
-    s->calib_pending = 0;
-    std::vector<int> st(count);
-    std::vector<u64> it(count);
-    HIP_TRY(hipMemcpyAsync(st.data(), s->d_status, count * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(it.data(), s->d_iters, count * sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+    int rc = APEMOST_HIP_OK;
+    while (k.in_flight && !rc) {
+        const hipError_t w = hipEventSynchronize(k.ev);
+        if (w != hipSuccess)
+            rc = fail(APEMOST_HIP_ERR_RUNTIME, "hipEventSynchronize failed: %s", hipGetErrorString(w));
+        else
+            rc = apemost_hip_calibrate_poll(s, nullptr);
+    }
+    k.open = false;
+    k.in_flight = false;
+    if (rc)
+        return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
-    int rc = check_handoff(s);
+    rc = check_handoff(s);
     if (rc)
         return rc;
     int worst = 0;
-    for (int i = 0; i < count; i++) {
+    for (int i = 0; i < k.count; i++) {
+        const CalibRec &r = k.h_rec[i];
+        const int st = r.stage == CAL_DONE ? r.status : -1;
         if (status)
-            status[i] = st[i];
+            status[i] = st;
         if (iters)
-            iters[i] = it[i];
-        if (st[i] && !worst)
-            worst = st[i];
+            iters[i] = r.sweeps;
+        if (st && !worst)
+            worst = st;
     }
     if (worst)
-        return fail(APEMOST_HIP_ERR_CALIBRATION, "calibration failed: %s",
-                    worst == 1 ? "a step width became too large" : "iteration limit reached");
+        return fail(APEMOST_HIP_ERR_CALIBRATION, "calibration %s",
+                    worst == 1 ? "failed: a step width became too large"
+                               : worst == 2 ? "failed: iteration limit reached" : "cancelled");
     return APEMOST_HIP_OK;
 }
 
@@ -2196,6 +1514,50 @@ extern "C" int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t firs
                                             int32_t *status, uint64_t *iters) {
     const int rc = apemost_hip_calibrate_begin(s, first, count, c, burn_in_only);
     return rc ? rc : apemost_hip_calibrate_end(s, status, iters);
+}
+
+extern "C" int apemost_hip_calibrate_progress(apemost_hip_sampler *s, double *rows, int32_t capacity_rows,
+                                              int32_t *n_rows) {
+    CHECK_S(s);
+    auto &k = s->cal;
+    if (k.open || !n_rows || capacity_rows < 0 || (capacity_rows > 0 && !rows))
+        return fail(APEMOST_HIP_ERR_INVALID, "calibrate_progress: bad arguments, or a calibration is still open");
+    *n_rows = 0;
+    if (k.progress_slot < 0 || !k.h_rec || k.progress_slot >= k.count)
+        return APEMOST_HIP_OK;
+    long long n = (long long)(k.h_rec[k.progress_slot].sweeps / k.cfg.iter_readjust);
+    const CalibRec &r = k.h_rec[k.progress_slot];
+    if (r.stage == CAL_ALL) // the sweeps of the last readjustment were not followed by their steps
+        n -= 1;
+    if (r.stage == CAL_DONE && r.status == 1)
+        n -= 1;
+    if (n > k.progress_cap)
+        n = k.progress_cap;
+    if (n < 0)
+        n = 0;
+    *n_rows = (int32_t)n;
+    const long long take = n < capacity_rows ? n : capacity_rows;
+    if (take > 0)
+        HIP_TRY(hipMemcpy(rows, k.d_progress, (size_t)take * (1 + 2 * s->cfg.n_par) * sizeof(double), hipMemcpyDeviceToHost));
+    return APEMOST_HIP_OK;
+}
+
+// segments and launches per workgroup shape of the latest calibration (bench, tests)
+extern "C" int apemost_hip_calibrate_stats(apemost_hip_sampler *s, uint64_t *segments, uint64_t *evaluations,
+                                           uint64_t launches_by_waves[9]) {
+    CHECK_S(s);
+    auto &k = s->cal;
+    if (segments)
+        *segments = k.segments;
+    if (evaluations) {
+        u64 sum = 0;
+        for (int i = 0; k.h_rec && i < k.count; i++)
+            sum += k.h_rec[i].evals;
+        *evaluations = sum;
+    }
+    if (launches_by_waves)
+        memcpy(launches_by_waves, k.launches_by_waves, sizeof k.launches_by_waves);
+    return APEMOST_HIP_OK;
 }
 
 static int rng_device(int device) {
@@ -2304,3 +1666,18 @@ extern "C" int apemost_hip_timer_end(apemost_hip_sampler *s, float *elapsed_ms, 
         *launches = s->launches - s->launches_at_begin;
     return APEMOST_HIP_OK;
 }
+
+// A build from this file alone (development and diagnostic builds: apemost_amd/build.py build_dev,
+// build_stamps) holds every model's kernels itself.
+#ifdef APEMOST_SINGLE_TU
+namespace apemost {
+template hipError_t model_dispatch<0>(int, const AnyOp &);
+template hipError_t model_dispatch<1>(int, const AnyOp &);
+template hipError_t model_dispatch<2>(int, const AnyOp &);
+template hipError_t model_dispatch<3>(int, const AnyOp &);
+template hipError_t model_dispatch<4>(int, const AnyOp &);
+template hipError_t model_dispatch<5>(int, const AnyOp &);
+template hipError_t model_dispatch<6>(int, const AnyOp &);
+template hipError_t model_dispatch<7>(int, const AnyOp &);
+} // namespace apemost
+#endif

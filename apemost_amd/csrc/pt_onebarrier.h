@@ -168,10 +168,10 @@ struct ObEngine {
         }
     }
     // owner and producer: the (parameter, attempt) lane layout and the RNG address
-    __device__ __forceinline__ void setup_lanes(const ChainShape &sh) {
+    __device__ __forceinline__ void setup_lanes(const ChainShape &sh, int c) {
         circular = sh.circular;
         seed = sh.seed;
-        g = (u64)(sh.chain_offset + blockIdx.x);
+        g = (u64)(sh.chain_offset + c);
         Q = 63 / n_par;
         grp = lane / Q;
         qidx = lane - grp * Q;
@@ -185,8 +185,8 @@ struct ObEngine {
             qidx = 1 << 30;
         }
     }
-    __device__ __forceinline__ void setup_lik(const DevArrays &, const ChainShape &sh, int) {
-        setup_lanes(sh); // (the first two candidate sets are made by likelihood waves)
+    __device__ __forceinline__ void setup_lik(const DevArrays &, const ChainShape &sh, int c) {
+        setup_lanes(sh, c); // (the first two candidate sets are made by likelihood waves)
         consts = sh.consts;
         x_abs_max = sh.x_abs_max;
         rows_in_regs = false;
@@ -392,7 +392,9 @@ struct ObEngine {
     // ---- owner ----
     // proposal attempts of the tick whose candidates are (cy, cs), from base point `from`:
     // first usable attempt per parameter -> LDS row `row`; returns the groups where none was usable
-    __device__ __forceinline__ u64 attempts(double from, double cy, double cs, double *row) const {
+    // which >= 0 (markov_chain_step_for, src/markov_chain.c:317-333): only that parameter is proposed,
+    // every other one keeps the base point's value
+    __device__ __forceinline__ u64 attempts(double from, double cy, double cs, double *row, int which = -1) const {
         double prop = from + stepw * cy * cs;
         bool inside = !(prop > hi || prop < lo);
         if (circular != 0) { // uniform: a non-default proposal law, or some parameter is circular
@@ -405,11 +407,14 @@ struct ObEngine {
                 prop = wrap_circular(prop, lo, hi);
             inside = inside || wrap;
         }
-        const bool ok = cand() && (cs == cs) && inside;
+        const bool active = cand() && (which < 0 || which == grp);
+        const bool ok = active && (cs == cs) && inside;
         const u64 mask = __ballot(ok);
         if (ok && (mask & lowmask) == 0)
             row[grp] = prop;
-        return __ballot(cand() && qidx == 0 && (mask & grpmask) == 0);
+        if (which >= 0 && cand() && !active && qidx == 0)
+            row[grp] = from;
+        return __ballot(active && qidx == 0 && (mask & grpmask) == 0);
     }
     // Engine::propose's rare path: none of the Q prepared attempts of a parameter worked -> the
     // whole wave tries 64 more at a time (attempt indices continue at Q, as in the serial loop of
@@ -451,12 +456,12 @@ struct ObEngine {
 
     // round start: the proposal of the first step from the current point (nothing to speculate on),
     // published as both variants; no partial sums yet, so the threshold slot says "take either"
-    __device__ __forceinline__ void owner_first() {
+    __device__ __forceinline__ void owner_first(int which = -1) {
         const double2 c0 = s_cand(tick)[lane];
         cand_y = c0.x;
         cand_s = c0.y;
         double *row = s_prop(0, 1);
-        const u64 failed = attempts(cur, cand_y, cand_s, row);
+        const u64 failed = attempts(cur, cand_y, cand_s, row, which);
         redraw(failed, tick, row);
         __builtin_amdgcn_wave_barrier();
         if (lane < n_par)
@@ -482,21 +487,46 @@ struct ObEngine {
         reject += n_steps - n_accepted;
         pacc += n_accepted;
         prej += n_steps - n_accepted;
+        n_accepted = 0;
     }
-    __device__ __forceinline__ void owner_results(int parity, double *sample) {
+    // the calibration's block boundaries (same meaning as Engine's)
+    __device__ __forceinline__ void check_best() {
+        if (prob > prob_best) {
+            prob_best = prob;
+            best = cur;
+        }
+    }
+    __device__ __forceinline__ void restart_from_best() {
+        cur = best;
+        prob = prob_best;
+    }
+    __device__ __forceinline__ void reset_accept_rejects() {
+        pacc = prej = 0;
+        accept = reject = 0;
+    }
+    // which >= 0: the step was a single-parameter update, which bumps that parameter's counters only
+    // (quirk Q5); check_best = false: burn_in() looks at the best point once per block of 200 steps
+    // (src/markov_chain.c:48-58), not after every step
+    __device__ __forceinline__ void owner_results(int parity, double *sample, int which = -1, bool check_best = true) {
         const double sum = tree(parity);
         accepted = sum < thr;
         // (the proposal's prior was computed for its threshold, a step ago: not again)
         const double prob_new = m.finish_known_prior(sum, beta_all, consts, prior_inflight);
         if (Model<kBase>::kHasPrior)
             prior = prior_inflight; // not restored on reject (quirk Q7)
-        n_accepted += accepted ? 1u : 0u; // the four counters move together here (all-parameter steps): settled at the end
+        if (which < 0) {
+            n_accepted += accepted ? 1u : 0u; // the four counters move together here (all-parameter steps): settled at the end
+        } else {
+            const u64 mine = which == grp ? 1u : 0u;
+            pacc += accepted ? mine : 0u;
+            prej += accepted ? 0u : mine;
+        }
         if (accepted) {
             if (cand())
                 cur = par_val;
             prob = prob_new;
         }
-        if (prob > prob_best) { // mcmc_check_best
+        if (check_best && prob > prob_best) { // mcmc_check_best
             prob_best = prob;
             best = cur;
         }
@@ -528,15 +558,15 @@ struct ObEngine {
         }
         m.load(row, n_par, x_abs_max);
     }
-    __device__ __forceinline__ void owner_publish(int parity) {
+    __device__ __forceinline__ void owner_publish(int parity, int which_next = -1) {
         const int next = parity ^ 1;
         // candidates of the next tick: published by the barrier that opened this step
         const double2 nx = s_cand(tick + 1)[lane];
         next_y = nx.x;
         next_s = nx.y;
         // the two proposals of the next step: from the proposal in flight, from the current point
-        fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0));
-        fail_r = attempts(cur, next_y, next_s, s_prop(next, 1));
+        fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0), which_next);
+        fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
         // S_max of the step in flight
         double prior_new = 0;
         if (Model<kBase>::kHasPrior)

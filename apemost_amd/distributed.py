@@ -103,9 +103,11 @@ class ShardedLadder:
         [n_rounds][n_swap][n_local][n_par+2] or None.  Rounds are batched into one engine launch
         up to the next swap attempt that needs a neighbour's record.  With finalize=False the last
         swap attempt stays pending and is applied at the start of the next call."""
-        limit = self.e.max_rounds_per_launch()
         r = 0
         while r < n_rounds:
+            # (asked anew for every launch: a refused cooperative launch or a failed hand-off takes the
+            # engine to one round per launch, and the next launch must not ask for more)
+            limit = self.e.max_rounds_per_launch()
             first_inside = self.round + (1 if self.swap_pending else 0)  # swap index after the launch's 1st round
             # the launch's first round, plus as many more as have their opening swap attempt inside
             # the shard (one call: a ctypes call per round would cost more than the round at n_swap 1)

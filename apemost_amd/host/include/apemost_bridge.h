@@ -26,6 +26,8 @@ unsigned int apemost_ladder_shard_first(const apemost_ladder *l, unsigned int k)
 void apemost_ladder_calc_model(apemost_ladder *l, unsigned int first, unsigned int count);
 int apemost_ladder_calibrate(apemost_ladder *l, unsigned int first, unsigned int count,
                              const apemost_hip_calib_config *c, int burn_in_only, int32_t *status);
+/* calibration_progress.data from the readjustment log of the latest calibration on this sampler */
+void apemost_write_calibration_progress(apemost_hip_sampler *s, unsigned int n_par);
 void apemost_ladder_run(apemost_ladder *l, unsigned long n_rounds, unsigned int n_swap, double **d_samples);
 /* cached one-chain twin used by the single-chain API (markov_chain_step & co) */
 apemost_ladder *apemost_single(mcmc *m);

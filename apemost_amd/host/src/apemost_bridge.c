@@ -479,19 +479,60 @@ void apemost_ladder_calc_model(apemost_ladder *l, unsigned int first, unsigned i
     }
 }
 
-/* markov_chain_calibrate() (or burn_in only) for chains [first, first+count): every shard's kernel
- * is launched before any result is awaited, so the devices calibrate concurrently.  status[count]
- * per chain; returns the first non-zero ABI return code (APEMOST_HIP_ERR_CALIBRATION, ...) or 0. */
+/* calibration_progress.data as the reference leaves it (src/markov_chain_calibrate.c:1052, 1141-1146):
+ * opened "w" by every chain's calibration, one line per parameter and readjustment; here written
+ * from the log the device kept for the chain named in apemost_hip_calib_config.progress_chain */
+void apemost_write_calibration_progress(apemost_hip_sampler *s, unsigned int n_par) {
+    int32_t n_rows = 0, k;
+    unsigned int i;
+    double *rows;
+    FILE *f;
+    apemost_hip_or_die(apemost_hip_calibrate_progress(s, NULL, 0, &n_rows), "calibration_progress.data");
+    rows = (double *)malloc(((size_t)n_rows + 1) * (1 + 2 * n_par) * sizeof(double));
+    if (n_rows > 0)
+        apemost_hip_or_die(apemost_hip_calibrate_progress(s, rows, n_rows, &n_rows), "calibration_progress.data");
+    f = fopen("calibration_progress.data", "w");
+    if (f != NULL) {
+        for (k = 0; k < n_rows; k++) {
+            const double *r = rows + (size_t)k * (1 + 2 * n_par);
+            for (i = 0; i < n_par; i++)
+                fprintf(f, "%d\t%lu\t%f\t%f\t%f\n", (int)i, (unsigned long)r[0], r[1 + 2 * i], r[2 + 2 * i], -1.);
+        }
+        fclose(f);
+    }
+    free(rows);
+}
+
+/* markov_chain_calibrate() (or burn_in only) for chains [first, first+count): every shard's first
+ * segment is launched before anything is awaited, then the shards are polled in turn, so the devices
+ * calibrate concurrently from the first launch to the last.  status[count] per chain; returns the
+ * first non-zero ABI return code (APEMOST_HIP_ERR_CALIBRATION, ...) or 0.  The readjustments of the
+ * last chain of the range go to calibration_progress.data: in the reference's (single-threaded)
+ * order that chain's calibration is the last one to open the file. */
 int apemost_ladder_calibrate(apemost_ladder *l, unsigned int first, unsigned int count,
                              const apemost_hip_calib_config *c, int burn_in_only, int32_t *status) {
     unsigned int k;
     int rc = APEMOST_HIP_OK;
+    const unsigned int last = first + count - 1;
+    apemost_hip_sampler *logger = NULL;
     for (k = 0; k < l->n_shards; k++) {
         const unsigned int a = first > l->lo[k] ? first : l->lo[k];
         const unsigned int b = first + count < l->lo[k + 1] ? first + count : l->lo[k + 1];
-        if (a < b)
-            apemost_hip_or_die(apemost_hip_calibrate_begin(l->s[k], (int)(a - l->lo[k]), (int)(b - a), c, burn_in_only),
+        if (a < b) {
+            apemost_hip_calib_config ck = *c;
+            ck.progress_chain = -1;
+            if (!burn_in_only && last >= a && last < b) {
+                ck.progress_chain = (int32_t)(last - l->lo[k]);
+                logger = l->s[k];
+            }
+            apemost_hip_or_die(apemost_hip_calibrate_begin(l->s[k], (int)(a - l->lo[k]), (int)(b - a), &ck, burn_in_only),
                                "markov_chain_calibrate");
+        }
+    }
+    if (l->n_shards > 1) { /* keep every device fed until all are done */
+        int32_t active = 1;
+        while (active > 0)
+            apemost_hip_or_die(apemost_hip_calibrate_wait_any(l->s, (int32_t)l->n_shards, &active), "markov_chain_calibrate");
     }
     for (k = 0; k < l->n_shards; k++) {
         const unsigned int a = first > l->lo[k] ? first : l->lo[k];
@@ -504,6 +545,8 @@ int apemost_ladder_calibrate(apemost_ladder *l, unsigned int first, unsigned int
                 rc = r;
         }
     }
+    if (logger != NULL)
+        apemost_write_calibration_progress(logger, l->n_par);
     return rc;
 }
 

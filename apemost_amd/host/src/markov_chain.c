@@ -87,9 +87,11 @@ void markov_chain_calibrate(mcmc *m, const unsigned int burn_in_iterations, doub
     uint64_t iters = 0;
     int rc;
     fill_calib(&c, burn_in_iterations, desired_acceptance_rate, max_ar_deviation, iter_limit, mul, adjust_step);
+    c.progress_chain = 0;
     mcmc_check(m);
     apemost_ladder_upload(l);
     rc = apemost_hip_calibrate_chains(apemost_ladder_sampler(l), 0, 1, &c, 0, &status, &iters);
+    apemost_write_calibration_progress(apemost_ladder_sampler(l), get_n_par(m)); /* markov_chain_calibrate.c:1052, 1141-1146 */
     if (rc == APEMOST_HIP_ERR_CALIBRATION) {
         /* the reference exits here too (markov_chain_calibrate.c:1107-1109, 1169-1173) */
         if (status == 1)

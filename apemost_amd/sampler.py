@@ -183,7 +183,16 @@ class HipSampler:
 
     # -- calibration ----------------------------------------------------------------
     def markov_chain_calibrate(self, first, count, cfg=None, burn_in_only=False):
-        cfg = cfg or capi.calib_defaults()
+        """markov_chain_calibrate() for chains [first, first+count).  Unless cfg names another chain
+        (progress_chain >= 0), the readjustments of the LAST chain of the range are logged: the
+        reference reopens calibration_progress.data "w" for every chain it calibrates
+        (src/markov_chain_calibrate.c:1052), so that chain's lines are the ones a single-threaded
+        run leaves behind (calibration_progress_text)."""
+        src = cfg or capi.calib_defaults()
+        cfg = capi.CalibConfig()
+        C.pointer(cfg)[0] = src
+        if cfg.progress_chain < 0 and not burn_in_only:
+            cfg.progress_chain = first + count - 1
         status = np.zeros(count, dtype=np.int32)
         iters = np.zeros(count, dtype=np.uint64)
         rc = self.L.apemost_hip_calibrate_chains(self._h, first, count, C.byref(cfg), int(burn_in_only),
@@ -191,7 +200,38 @@ class HipSampler:
                                                  iters.ctypes.data_as(C.POINTER(C.c_uint64)))
         if rc not in (capi.OK, capi.ERR_CALIBRATION):
             capi.check(rc)
+        if not burn_in_only:
+            self._progress_text = self._format_progress(self.calibrate_progress())
         return status, iters
+
+    def _format_progress(self, rows):
+        """the line format of src/markov_chain_calibrate.c:1143-1146: "%d\t%lu\t%f\t%f\t%f\n" of
+        (parameter, iter, normalised step, accept rate, -1.)"""
+        return "".join("%d\t%d\t%f\t%f\t%f\n" % (i, int(r[0]), r[1 + 2 * i], r[2 + 2 * i], -1.0)
+                       for r in rows for i in range(self.n_par))
+
+    def calibration_progress_text(self):
+        """contents of calibration_progress.data after the calibrations made so far"""
+        return getattr(self, "_progress_text", "")
+
+    def calibrate_progress(self):
+        """rows (iter, then (normalised step, accept rate) per parameter) of the chain named by
+        cfg.progress_chain in the latest calibration: what the reference writes to
+        calibration_progress.data (src/markov_chain_calibrate.c:1143-1146)"""
+        n = C.c_int32(0)
+        capi.check(self.L.apemost_hip_calibrate_progress(self._h, None, 0, C.byref(n)))
+        rows = np.zeros((n.value, 1 + 2 * self.n_par))
+        if n.value:
+            capi.check(self.L.apemost_hip_calibrate_progress(self._h, rows.ctypes.data_as(C.POINTER(C.c_double)),
+                                                             n.value, C.byref(n)))
+        return rows
+
+    def calibrate_stats(self):
+        """(segments, likelihood evaluations, launches per waves-per-chain) of the latest calibration"""
+        seg, ev = C.c_uint64(0), C.c_uint64(0)
+        by = (C.c_uint64 * 9)()
+        capi.check(self.L.apemost_hip_calibrate_stats(self._h, C.byref(seg), C.byref(ev), by))
+        return seg.value, ev.value, {w: int(by[w]) for w in range(9) if by[w]}
 
     def calibrate_first(self, cfg=None):
         """calibrate_first(): calc_model(chain 0) then markov_chain_calibrate(chain 0)."""

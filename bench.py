@@ -183,6 +183,9 @@ def main():
         calib_wall = time.perf_counter() - tc
         calibrated = int((status == 0).sum())
         calibration = calibration_block(calib_wall, status, iters, ccfg, w.n_par)
+        seg, ev, by_waves = s.calibrate_stats()
+        calibration.update({"segments": seg, "evaluations_counted_on_device": ev,
+                            "launches_by_waves_per_chain": {str(k): v for k, v in by_waves.items()}})
         if a.calib_dump and rank == 0:
             json.dump({"config": a.config, "burn_in": a.burn_in, "wall_s": calib_wall, "status": status.tolist(),
                        "sweeps": [int(x) for x in iters]}, open(a.calib_dump, "w"))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APEMOST_HIP_ABI_VERSION 2
+#define APEMOST_HIP_ABI_VERSION 3
 
 enum {
     APEMOST_HIP_OK = 0,
@@ -170,6 +170,11 @@ typedef struct {
     double max_ar_deviation;     /* MAX_AR_DEVIATION */
     double mul;                  /* MUL */
     double adjust_step;          /* DEFAULT_ADJUST_STEP */
+    int32_t progress_chain;      /* local chain whose readjustments are logged for calibration_progress.data
+                                  * (src/markov_chain_calibrate.c:1143-1146; the reference reopens that file
+                                  * "w" for every chain, so the last chain calibrated is the one whose lines
+                                  * survive), or -1 */
+    int32_t reserved;            /* 0 */
 } apemost_hip_calib_config;
 
 /* ---- environment ---------------------------------------------------------- */
@@ -312,11 +317,34 @@ int apemost_hip_calibrate_chains(apemost_hip_sampler *s, int32_t first, int32_t 
                                  const apemost_hip_calib_config *c, int burn_in_only,
                                  int32_t *status, uint64_t *iters);
 
-/* the same in two halves, for hosts that drive several devices from one thread: begin launches
- * (asynchronous), end waits and collects status/iters of the chains begin named */
+/* The same in pieces.  The calibration runs as a sequence of launches ("segments"): a chain's trip
+ * count is data-dependent, so every segment ends after a bounded number of likelihood evaluations per
+ * chain, the chains that are done drop out, and the survivors are launched again -- with more
+ * wavefronts per chain as they get fewer.  Results do not depend on where the segments are cut.
+ *   begin  launches the first segment (asynchronous);
+ *   poll   never blocks: if the segment in flight has ended, collects it and launches the next one;
+ *          *active = chains still calibrating.  Hosts that drive several devices from one thread poll
+ *          them in turn, and a host with a SIGINT handler polls between looks at its flag;
+ *   cancel no further segments: end then returns with status -1 for the chains that were not done
+ *          (their state is a consistent point of their calibration);
+ *   end    polls and waits until no chain is left, then hands out status/iters of the chains begin named. */
 int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first, int32_t count,
                                 const apemost_hip_calib_config *c, int burn_in_only);
+int apemost_hip_calibrate_poll(apemost_hip_sampler *s, int32_t *active);
+int apemost_hip_calibrate_cancel(apemost_hip_sampler *s);
+/* several samplers (one per device) calibrating at once, driven by one thread: returns when a segment
+ * of one of them has ended and been followed up, or none has chains left; *active_total = chains
+ * still calibrating over all of them */
+int apemost_hip_calibrate_wait_any(apemost_hip_sampler **samplers, int32_t n, int32_t *active_total);
 int apemost_hip_calibrate_end(apemost_hip_sampler *s, int32_t *status, uint64_t *iters);
+/* the readjustment log of apemost_hip_calib_config.progress_chain after calibrate_end: row k =
+ * { iter, then per parameter (normalised step width, acceptance rate) } as the reference prints them
+ * after its k-th readjustment; rows [capacity_rows][1 + 2 n_par], *n_rows = rows that exist */
+int apemost_hip_calibrate_progress(apemost_hip_sampler *s, double *rows, int32_t capacity_rows, int32_t *n_rows);
+/* the latest calibration in numbers: segments launched, likelihood evaluations of all its chains, and
+ * launches per workgroup shape (index = likelihood wavefronts per chain) */
+int apemost_hip_calibrate_stats(apemost_hip_sampler *s, uint64_t *segments, uint64_t *evaluations,
+                                uint64_t launches_by_waves[9]);
 
 /* ---- test hooks: device RNG conformance ------------------------------------ */
 /* n raw 32-bit outputs of rocRAND philox4x32_10 (seed, subsequence, offset) */

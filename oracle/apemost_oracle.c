@@ -8,6 +8,7 @@
 #include "apemost_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -796,6 +797,13 @@ void orc_burn_in(orc_state *s, orc_rng *r, int c, unsigned int burn_in_iteration
 }
 
 /* markov_chain_calibrate_orig: src/markov_chain_calibrate.c:1039-1180 */
+/* calibration_progress.data (src/markov_chain_calibrate.c:1052, 1141-1146): the reference opens the
+ * file "w" at the start of EVERY chain's calibration, in the current directory, and appends one line
+ * per parameter at every readjustment.  The oracle writes it only when a path has been set (NULL:
+ * off, the default); with several threads the chains clobber one file, as in the reference. */
+static const char *orc_progress_path = NULL;
+void orc_set_progress_path(const char *path) { orc_progress_path = path; }
+
 int orc_calibrate_orig(orc_state *s, orc_rng *r, int c, const orc_calib_cfg *cfg,
                        uint64_t *iters_out) {
     const int n = s->n_par;
@@ -806,6 +814,7 @@ int orc_calibrate_orig(orc_state *s, orc_rng *r, int c, const orc_calib_cfg *cfg
     unsigned long iter = 0, subiter;
     int nchecks_without_rescaling = 0, reached_perfection = 0, rescaled, p;
     int status = ORC_CALIB_OK;
+    FILE *progress_plot_file = orc_progress_path ? fopen(orc_progress_path, "w") : NULL;
 
     for (p = 0; p < n; p++)
         step[p] *= cfg->adjust_step;
@@ -851,6 +860,12 @@ int orc_calibrate_orig(orc_state *s, orc_rng *r, int c, const orc_calib_cfg *cfg
                 orc_markov_chain_step(s, r, c);
                 orc_check_best(s, c);
             }
+            if (progress_plot_file) {
+                for (p = 0; p < n; p++) /* :1141-1146 */
+                    fprintf(progress_plot_file, "%d\t%lu\t%f\t%f\t%f\n", p, iter, step[p] / (pmax[p] - pmin[p]),
+                            (double)pa[p] / ((double)pr[p] + (double)pa[p]), -1.);
+                fflush(progress_plot_file);
+            }
             delta = (double)s->accept[c] / (double)(s->accept[c] + s->reject[c]) -
                     cfg->target_global;
             if ((delta < 0 ? -delta : delta) < cfg->max_ar_deviation) {
@@ -873,6 +888,8 @@ int orc_calibrate_orig(orc_state *s, orc_rng *r, int c, const orc_calib_cfg *cfg
     }
     orc_reset_accept_rejects(s, c);
 done:
+    if (progress_plot_file)
+        fclose(progress_plot_file);
     if (iters_out)
         *iters_out = iter;
     return status;

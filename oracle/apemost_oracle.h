@@ -202,6 +202,10 @@ void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n
                      double *samples, int n_threads);
 
 void orc_burn_in(orc_state *s, orc_rng *r, int chain, unsigned int burn_in_iterations);
+/* where orc_calibrate_orig writes the reference's calibration_progress.data
+ * (src/markov_chain_calibrate.c:1052, 1141-1146); NULL = nowhere (default).  The string is kept by
+ * pointer. */
+void orc_set_progress_path(const char *path);
 int orc_calibrate_orig(orc_state *s, orc_rng *r, int chain, const orc_calib_cfg *cfg,
                        uint64_t *iters_out);
 int orc_markov_chain_calibrate(orc_state *s, orc_rng *r, int chain, const orc_calib_cfg *cfg,

@@ -131,6 +131,8 @@ def lib():
             f = getattr(L, name)
             f.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.c_int, C.POINTER(CalibCfg), _up]
             f.restype = C.c_int
+        L.orc_set_progress_path.argtypes = [C.c_char_p]
+        L.orc_set_progress_path.restype = None
         L.orc_calibrate_first.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.POINTER(CalibCfg)]
         L.orc_calibrate_first.restype = C.c_int
         L.orc_calibrate_rest.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.POINTER(CalibCfg),
@@ -359,6 +361,17 @@ def markov_chain_calibrate(ladder, rng, chain, cfg):
     status = lib().orc_markov_chain_calibrate(C.byref(st), C.byref(rng.c), chain, C.byref(cfg),
                                               C.byref(iters))
     return status, iters.value
+
+
+_progress_path = None
+
+
+def set_progress_path(path):
+    """calibration_progress.data of the calibrations that follow (None: none); every chain's
+    calibration truncates it, as in the reference"""
+    global _progress_path
+    _progress_path = None if path is None else os.fsencode(str(path))   # kept alive: the C side holds the pointer
+    lib().orc_set_progress_path(_progress_path)
 
 
 def calibrate_first(ladder, rng, cfg):

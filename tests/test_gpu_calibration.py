@@ -196,3 +196,170 @@ def test_config5_shard_size_with_device_calibration():
         np.testing.assert_allclose(ca.params[c], lad.params[0], rtol=1e-9)
         np.testing.assert_allclose(ca.prob_best[c], lad.prob_best[0], rtol=1e-9)
         assert ca.ticks[c] == rng.ticks[0]
+
+
+# ---- round 3: the calibration as a sequence of launches -----------------------------------------
+def _oracle_calibration(w, n_chain, seed, ocfg, progress_path=None):
+    st, lad, rng = make_pair(w, n_chain, seed=seed, init_prob=True)
+    orc.set_progress_path(progress_path)
+    try:
+        res = [orc.markov_chain_calibrate(lad, rng, c, ocfg) for c in range(n_chain)]
+    finally:
+        orc.set_progress_path(None)
+    return st, lad, rng, res
+
+
+@pytest.mark.parametrize("name,waves", [("simplesin", 1), ("simplesin", 4), ("pulse", 8), ("pulse_vrot", 2), ("sine3", 4)])
+def test_calibration_cut_at_every_block_matches_oracle(name, waves, monkeypatch):
+    """APEMOST_CALIB_SEGMENT_EVALS=1 ends every launch after ONE block (200 burn-in steps, 200 sweeps, or
+    the 200 steps behind them): the whole state of a calibration -- stage, burn-in position, sweeps,
+    rat_limit, the no-rescaling count, the saved step widths, and the chain -- goes through HBM between
+    any two blocks.  Same oracle run as one launch would have to match; waves 4 and 8 are the
+    one-barrier kernel (single-parameter sweeps with both next proposals prepared ahead)."""
+    monkeypatch.setenv("APEMOST_CALIB_SEGMENT_EVALS", "1")
+    w = small_workloads()[name]
+    n_chain = 3
+    dcfg, ocfg = _cfgs()
+    st, lad, rng, res = _oracle_calibration(w, n_chain, 17, ocfg)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=17, waves_per_chain=waves)
+    s.set_state(st)
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    segments, evals, by_waves = s.calibrate_stats()
+    assert [(int(a), int(b)) for a, b in zip(status, iters)] == res
+    assert_match(s.get_state(), lad, rng, what="segmented calibrate %s waves=%d" % (name, waves))
+    blocks = max(3 + 2 * (it // 200) for _, it in res)       # burn-in 600 = 3 blocks, then two per readjustment
+    assert segments == blocks and list(by_waves) == [waves]
+    assert evals == sum(600 + it * w.n_par + (it // 200) * 200 for _, it in res)
+    s.close()
+
+
+def test_tail_of_a_calibration_gets_more_waves_per_chain_and_still_matches_oracle(monkeypatch):
+    """The survivors of a calibration are launched again with the workgroup shape the engine would
+    choose for a ladder of that many chains.  800 chains start with one wave each; the chains that
+    need the most sweeps end the calibration with more (two from 768 chains down, the four-wave
+    one-barrier kernel from 512 down).  Whatever the cut,
+    status and sweep counts equal the oracle's for every chain checked (first to finish, median,
+    last to finish, and a sample in between)."""
+    monkeypatch.setenv("APEMOST_CALIB_SEGMENT_EVALS", "1000")     # a readjustment per launch
+    w = wl.simplesin(n_data=512, n_chain=800)
+    n_chain = 800
+    dcfg, ocfg = _cfgs(burn=400)
+    st, _, _ = make_pair(w, n_chain, seed=23, init_prob=False)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=23)
+    assert s.geometry[0] == 1
+    s.set_state(st)
+    s.calc_model(0, n_chain)
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    dev = s.get_state()
+    segments, _, by_waves = s.calibrate_stats()
+    assert by_waves.get(1, 0) > 0 and len(by_waves) >= 2 and segments == sum(by_waves.values()), by_waves
+    order = np.argsort(iters, kind="stable")
+    picks = sorted(set([int(order[0]), int(order[n_chain // 2]), int(order[-1]), int(order[-2])] + list(range(0, n_chain, 97))))
+    for c in picks:
+        one = st.slice(c, c + 1)
+        lad = orc.Ladder(w.model, 1, 4, w.data, chain_offset=c)
+        to_oracle(one, lad)
+        rng = orc.Rng(orc.RNG_STREAMS, 23, lad)
+        orc.calc_model(lad, 0)
+        assert (int(status[c]), int(iters[c])) == orc.markov_chain_calibrate(lad, rng, 0, ocfg), c
+        np.testing.assert_allclose(dev.step[c], lad.step[0], rtol=1e-9)
+        np.testing.assert_allclose(dev.params[c], lad.params[0], rtol=1e-9)
+        np.testing.assert_allclose(dev.prob_best[c], lad.prob_best[0], rtol=1e-9)
+        assert dev.ticks[c] == rng.ticks[0]
+    s.close()
+
+
+@pytest.mark.parametrize("waves", [1, 4])
+def test_calibration_progress_log_equals_the_oracles_file(waves, tmp_path):
+    """calibration_progress.data (src/markov_chain_calibrate.c:1052, 1141-1146): the reference reopens
+    the file "w" for every chain, so after a single-threaded pass over the chains it holds the lines
+    of the last one.  The device logs that chain's readjustments; the text must equal the file the
+    oracle writes, byte for byte (step widths move by exact factors, accept rates are k/200)."""
+    w = small_workloads()["simplesin"]
+    n_chain = 3
+    dcfg, ocfg = _cfgs()
+    path = tmp_path / "calibration_progress.data"
+    st, lad, rng, res = _oracle_calibration(w, n_chain, 29, ocfg, progress_path=path)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=29, waves_per_chain=waves)
+    s.set_state(st)
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    assert [(int(a), int(b)) for a, b in zip(status, iters)] == res
+    text = s.calibration_progress_text()
+    assert text == path.read_text()
+    assert len(text.splitlines()) == 4 * (res[-1][1] // 200) and text.splitlines()[0].startswith("0\t200\t")
+    # any chain of the range can be the logged one
+    mid = capi.calib_defaults(burn_in_iterations=BURN, iter_limit=LIMIT, progress_chain=1)
+    s.set_state(st)
+    s.set_state(LadderState(n_chain, 4), ("ticks",))       # rewind the RNG addresses
+    s.markov_chain_calibrate(0, n_chain, mid)
+    rows = s.calibrate_progress()
+    assert rows.shape == (res[1][1] // 200, 9) and rows[-1, 0] == res[1][1]
+    with pytest.raises(capi.ApemostHipError):
+        s.markov_chain_calibrate(0, 2, capi.calib_defaults(progress_chain=2))   # outside the range
+    s.close()
+
+
+def test_calibration_can_be_polled_and_cancelled(monkeypatch):
+    """begin / poll / cancel / end: poll never blocks and reports the chains still calibrating; after
+    cancel the chains that were not done come back with status -1 in a consistent state (whole
+    blocks), and the sampler calibrates again afterwards"""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("APEMOST_CALIB_SEGMENT_EVALS", "1")
+    w = small_workloads()["simplesin"]
+    n_chain = 4
+    st, lad, rng = make_pair(w, n_chain, seed=41, init_prob=True)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=41)
+    s.set_state(st)
+    dcfg, ocfg = _cfgs()
+    L = s.L
+    capi.check(L.apemost_hip_calibrate_begin(s._h, 0, n_chain, C.byref(dcfg), 0))
+    assert L.apemost_hip_calibrate_begin(s._h, 0, n_chain, C.byref(dcfg), 0) == capi.ERR_INVALID
+    active = C.c_int32(-1)
+    seen = 0
+    while s.calibrate_stats()[0] < 6:                  # a few segments on
+        capi.check(L.apemost_hip_calibrate_poll(s._h, C.byref(active)))
+        assert 0 < active.value <= n_chain
+        seen += 1
+        time.sleep(0.001)
+    capi.check(L.apemost_hip_calibrate_cancel(s._h))
+    status = np.zeros(n_chain, dtype=np.int32)
+    iters = np.zeros(n_chain, dtype=np.uint64)
+    rc = L.apemost_hip_calibrate_end(s._h, status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     iters.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == capi.ERR_CALIBRATION and np.all(status == -1) and b"cancelled" in L.apemost_hip_last_error()
+    part = s.get_state()
+    assert np.all(part.ticks % 200 == 0) and np.all(part.ticks >= 600) and np.all(iters % 200 == 0)
+    assert L.apemost_hip_calibrate_poll(s._h, C.byref(active)) == capi.ERR_INVALID      # nothing open
+    # a fresh calibration on the same sampler equals the oracle's
+    s.set_state(st)
+    s.set_state(LadderState(n_chain, 4), ("ticks",))
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    for c in range(n_chain):
+        assert (int(status[c]), int(iters[c])) == orc.markov_chain_calibrate(lad, rng, c, ocfg)
+    assert_match(s.get_state(), lad, rng, what="calibrate after cancel")
+    s.close()
+
+
+def test_data_vector_between_the_two_kernels_lds_limits_is_staged_correctly():
+    """n_data = 3450 with the data vector forced into LDS: 9536 + 55200 B for the two-phase kernels is
+    under 64 KiB, 10560 + 55200 B for the one-barrier kernels is over it, so only the latter need the
+    opt-in for large dynamic LDS (the opt-in was decided on the two-phase footprint alone)"""
+    import torch
+    w = wl.simplesin(n_data=3450, n_chain=8)
+    n_chain = 8
+    st, lad, rng = make_pair(w, n_chain, seed=3, init_prob=True)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=3, waves_per_chain=4, lds_policy=1)
+    assert s.geometry == (4, True)
+    s.set_state(st)
+    d = torch.zeros((3 * 9, n_chain, 6), dtype=torch.float64, device="cuda")
+    s.run_sampler(3, 9, d.data_ptr())
+    s.synchronize()
+    ref = orc.run_sampler(lad, rng, 3, 9, record=True)
+    assert_match(s.get_state(), lad, rng, what="n_data 3450 in LDS")
+    np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-9)
+    dcfg, ocfg = _cfgs(burn=200)
+    status, iters = s.markov_chain_calibrate(0, 2, dcfg)
+    for c in range(2):
+        assert (int(status[c]), int(iters[c])) == orc.markov_chain_calibrate(lad, rng, c, ocfg)
+    s.close()

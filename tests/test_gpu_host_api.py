@@ -424,8 +424,11 @@ def test_c_application_built_with_the_variant_macros_equals_python_mirror_and_or
                        ccflags="-DN_BETA=%d -DBURN_IN_ITERATIONS=%d -DMAX_ITERATIONS=%d -DPROPOSAL_LOGISTIC -DRANDOMSWAP "
                                "-DADAPT -DTARGET_ACCEPTANCE_RATE=0.4" % (n_beta, burn, iters))
     env = dict(os.environ, APEMOST_SEED="7")
+    c_progress = {}
     for phase in ("calibrate_first", "calibrate_rest", "run"):
         subprocess.check_call([exe, phase], cwd=str(work), env=env, stdout=subprocess.DEVNULL)
+        c_progress[phase] = (work / "calibration_progress.data").read_text()
+    assert c_progress["run"] == c_progress["calibrate_rest"]      # the run phase leaves the file alone
     c_calib = (work / "calibration_results").read_text()
     c_amp = np.loadtxt(str(work / "amplitude-chain-0.prob.dump"))
     c_accept = (work / "acceptance_rate.dump").read_text().strip().splitlines()[-1].split()
@@ -437,6 +440,8 @@ def test_c_application_built_with_the_variant_macros_equals_python_mirror_and_or
     s = HipSampler(w.model, 4, 1, data, seed=7, flags=flags, adapt_target=0.4)
     s.set_state(mk().slice(0, 1))
     assert s.calibrate_first(dcfg) == 0
+    # calibration_progress.data (src/markov_chain_calibrate.c:1143-1146): chain 0's readjustments
+    assert s.calibration_progress_text() == c_progress["calibrate_first"] != ""
     first = s.get_state()
     s.close()
     s = HipSampler(w.model, 4, n_beta, data, seed=7, flags=flags, adapt_target=0.4)
@@ -447,6 +452,9 @@ def test_c_application_built_with_the_variant_macros_equals_python_mirror_and_or
     status, beta_0, _ = s.calibrate_rest(dcfg)
     assert status == 0
     assert s.get_state().calibration_results_text() == c_calib
+    # ... and after calibrate_rest the lines of the ladder's last chain (the last one to reopen the file)
+    assert s.calibration_progress_text() == c_progress["calibrate_rest"] != c_progress["calibrate_first"]
+    assert c_progress["calibrate_rest"].startswith("0\t200\t")
     s.close()
 
     s = HipSampler(w.model, 4, n_beta, data, seed=7, flags=flags, adapt_target=0.4)
