@@ -15,7 +15,7 @@ ABI_VERSION = 3
 FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH, FLAG_TWO_BARRIER_STEP = 1, 2, 4
 # the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP, -DADAPT)
 FLAG_PROPOSAL_LOGISTIC, FLAG_PROPOSAL_UNIFORM, FLAG_RANDOMSWAP, FLAG_ADAPT = 8, 16, 32, 64
-FLAG_TEST_REFUSE_COOPERATIVE = 128   # test hook (include/apemost_hip.h)
+FLAG_TEST_REFUSE_COOPERATIVE, FLAG_TEST_WITHHOLD_PUBLISH = 128, 256   # test hooks (include/apemost_hip.h)
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_CALIBRATION = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -56,7 +56,7 @@ class CalibConfig(C.Structure):
 EXPORTS = [
     "apemost_hip_last_error", "apemost_hip_abi_version", "apemost_hip_device_count",
     "apemost_hip_device_info", "apemost_hip_create", "apemost_hip_destroy", "apemost_hip_synchronize",
-    "apemost_hip_stream", "apemost_hip_waves_per_chain", "apemost_hip_set_chain_offset", "apemost_hip_set_data", "apemost_hip_set_state",
+    "apemost_hip_stream", "apemost_hip_waves_per_chain", "apemost_hip_launch_policy", "apemost_hip_set_chain_offset", "apemost_hip_set_data", "apemost_hip_set_state",
     "apemost_hip_get_state", "apemost_hip_set_round", "apemost_hip_get_round", "apemost_hip_calc_model",
     "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_launch_rounds", "apemost_hip_max_rounds_per_launch",
     "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
@@ -104,6 +104,7 @@ def lib():
     L.apemost_hip_synchronize.argtypes = [vp]
     L.apemost_hip_stream.argtypes = [vp, C.POINTER(vp)]
     L.apemost_hip_waves_per_chain.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.apemost_hip_launch_policy.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.apemost_hip_set_data.argtypes = [vp, _dp]
     L.apemost_hip_set_state.argtypes = [vp, C.POINTER(StateView)]
     L.apemost_hip_get_state.argtypes = [vp, C.POINTER(StateView)]

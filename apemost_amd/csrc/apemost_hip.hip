@@ -270,6 +270,7 @@ extern "C" int apemost_hip_device_info(int device, char *name, size_t name_len, 
 }
 
 static int enable_big_lds(apemost_hip_sampler *s, int waves);
+static int max_rounds_per_launch(apemost_hip_sampler *s);
 template <bool LDS>
 static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks);
 static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data);
@@ -406,6 +407,8 @@ static int create_body(apemost_hip_sampler *s) {
     if (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM)
         s->sh.circular |= (u64)kProposalFlat << kProposalShift;
     s->sh.variant = (cfg->flags & APEMOST_HIP_FLAG_RANDOMSWAP) ? kVariantRandomSwap : 0;
+    if (cfg->flags & APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH)
+        s->sh.variant |= kVariantTestWithhold;
     s->kmodel = cfg->model + ((cfg->flags & (APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC | APEMOST_HIP_FLAG_PROPOSAL_UNIFORM |
                                              APEMOST_HIP_FLAG_RANDOMSWAP))
                                   ? kVariantModel
@@ -484,7 +487,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH |
                        APEMOST_HIP_FLAG_TWO_BARRIER_STEP | APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC |
                        APEMOST_HIP_FLAG_PROPOSAL_UNIFORM | APEMOST_HIP_FLAG_RANDOMSWAP | APEMOST_HIP_FLAG_ADAPT |
-                       APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE))
+                       APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE | APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH))
         return fail(APEMOST_HIP_ERR_INVALID, "unknown bits in flags: 0x%x", (unsigned)cfg->flags);
     if ((cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC) && (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM))
         return fail(APEMOST_HIP_ERR_INVALID, "PROPOSAL_LOGISTIC and PROPOSAL_UNIFORM are alternatives");
@@ -605,6 +608,18 @@ extern "C" int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, i
         *waves = s->waves;
     if (data_in_lds)
         *data_in_lds = s->lds_data ? 1 : 0;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_launch_policy(apemost_hip_sampler *s, int32_t *one_barrier, int32_t *cooperative,
+                                         int32_t *max_rounds) {
+    CHECK_S(s);
+    if (one_barrier)
+        *one_barrier = s->one_barrier ? 1 : 0;
+    if (cooperative)
+        *cooperative = (s->cooperative && s->resident_ok && !s->handoff_failed) ? 1 : 0;
+    if (max_rounds)
+        *max_rounds = max_rounds_per_launch(s);
     return APEMOST_HIP_OK;
 }
 
@@ -1207,12 +1222,19 @@ extern "C" int apemost_hip_run_shards(apemost_hip_sampler **sh, int32_t n_shards
     if (next != sh[0]->cfg.n_chains_global)
         return fail(APEMOST_HIP_ERR_INVALID, "run_shards: the shards cover %lld of %lld chains", (long long)next,
                     (long long)sh[0]->cfg.n_chains_global);
+    // Shards that share a device launch their grids side by side on separate streams: the residency
+    // every multi-round launch relies on (a workgroup may wait for its swap partner inside the launch)
+    // was established for one grid alone on the device, so such shards hold one round per launch.
+    bool device_shared = false;
+    for (int j = 0; j < n_shards; j++)
+        for (int i = 0; i < j; i++)
+            device_shared = device_shared || sh[i]->cfg.device == sh[j]->cfg.device;
     int rc;
     for (uint64_t r = 0; r < n_rounds || (r == n_rounds && sh[0]->swap_pending);) {
         const bool finalise = r == n_rounds; // the swap attempt that closes the last round
         const int pending = sh[0]->swap_pending;
         const u64 first_inside = sh[0]->round + (pending ? 1 : 0);
-        uint64_t limit = finalise || n_swap == 0 ? 1 : n_rounds - r;
+        uint64_t limit = finalise || n_swap == 0 || device_shared ? 1 : n_rounds - r;
         for (int j = 0; j < n_shards; j++)
             if ((uint64_t)max_rounds_per_launch(sh[j]) < limit)
                 limit = (uint64_t)max_rounds_per_launch(sh[j]);

@@ -157,10 +157,15 @@ __device__ __forceinline__ u64 ld_agent(const u64 *p) {
 }
 // bounded relaxed poll by one wave on one word; on timeout the launch's timeout word is set and
 // the host reports the failure (results of that launch are void)
-__device__ __forceinline__ bool wait_at_least(const u64 *word, u64 want, u64 *timeout_word) {
+// (kVariantTestShortWaits, a test hook: a few thousand polls, so that the timeout path can be walked
+// in milliseconds -- apemost_hip.h APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH)
+__device__ __forceinline__ unsigned handoff_spins(const ChainShape &sh) {
+    return (sh.variant & kVariantTestWithhold) ? 20000u : 8000000u;
+}
+__device__ __forceinline__ bool wait_at_least(const u64 *word, u64 want, u64 *timeout_word, unsigned max_spins) {
     for (unsigned spins = 0; ld_agent(word) < want; spins++) {
         __builtin_amdgcn_s_sleep(2);
-        if (spins > 8000000u) {
+        if (spins > max_spins) {
             st_agent(timeout_word, 1);
             return false;
         }
@@ -256,7 +261,7 @@ __device__ __forceinline__ void wait_for_reader(const DevArrays &d, const ChainS
                                                 int half) {
     const int p = memo.partner(half);
     if (p >= 0 && p < sh.n_chains)
-        wait_at_least(d.acked() + p, memo.index(half) + 1, d.timeout_word());
+        wait_at_least(d.acked() + p, memo.index(half) + 1, d.timeout_word(), handoff_spins(sh));
 }
 
 // swap attempt at the start of a launch: both records were stored by the previous launch (or
@@ -305,9 +310,12 @@ __device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const C
         st_agent(d.prob_best(half) + row, e.prob_best);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every payload store of this wave has left
-    if (e.lane == 0)
+    // (test hook: the lower chain of the pair keeps the publish of swap attempt 3 to itself, so its
+    // partner's bounded wait runs out)
+    const bool withhold = (sh.variant & kVariantTestWithhold) && swap_index == 3 && g == a;
+    if (e.lane == 0 && !withhold)
         st_agent(d.published() + c, swap_index + 1);
-    if (!wait_at_least(d.published() + partner, swap_index + 1, d.timeout_word()))
+    if (!wait_at_least(d.published() + partner, swap_index + 1, d.timeout_word(), handoff_spins(sh)))
         return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     swap_apply(e, d, sh, c, half, swap_index, true);

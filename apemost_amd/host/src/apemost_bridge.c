@@ -139,8 +139,11 @@ static int default_device(void) {
     return dev ? atoi(dev) : 0;
 }
 
+/* run_ladder: the sampler of a phase that goes through run_sampler().  The reference calls adapt()
+ * (-DADAPT) from run_sampler's loop only (src/parallel_tempering.c:404): the one-chain twin behind
+ * markov_chain_step() & co and the sampler that identifies the likelihood never adapt. */
 static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned int n_chains, long chain_offset,
-                                           long n_global, int device) {
+                                           long n_global, int device, int run_ladder) {
     apemost_hip_config cfg;
     apemost_hip_sampler *s = NULL;
     const char *waves = getenv("APEMOST_WAVES"), *flags = getenv("APEMOST_FLAGS");
@@ -172,7 +175,10 @@ static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned in
     cfg.flags |= APEMOST_HIP_FLAG_RANDOMSWAP;
 #endif
 #ifdef ADAPT
-    cfg.flags |= APEMOST_HIP_FLAG_ADAPT;
+    if (run_ladder)
+        cfg.flags |= APEMOST_HIP_FLAG_ADAPT;
+#else
+    (void)run_ladder;
 #endif
     cfg.adapt_target = TARGET_ACCEPTANCE_RATE;
     apemost_hip_or_die(apemost_hip_create(&cfg, &s), "apemost_hip_create");
@@ -260,7 +266,7 @@ int apemost_detect_model(mcmc *m) {
             continue;
         if (forced && strcmp(forced, model_name(model)) != 0)
             continue;
-        s = create_sampler(m, model, 1, 0, 1, default_device());
+        s = create_sampler(m, model, 1, 0, 1, default_device(), 0);
         apemost_hip_or_die(apemost_hip_loglike(s, DETECT_POINTS, pts, beta, dev_prob, dev_prior),
                            "apemost_hip_loglike");
         apemost_hip_destroy(s);
@@ -445,7 +451,7 @@ apemost_ladder *apemost_ladder_open(mcmc **chains, unsigned int n_chains) {
         l->lo[k] = (unsigned int)(((unsigned long)k * n_chains + shards - 1) / shards);
     for (k = 0; k < shards; k++)
         l->s[k] = create_sampler(chains[0], model, l->lo[k + 1] - l->lo[k], (long)l->lo[k], (long)n_chains,
-                                 devices[k]);
+                                 devices[k], 1);
     alloc_view(l);
     apemost_ladder_upload(l);
     for (k = 0; k < shards; k++)
@@ -573,7 +579,7 @@ apemost_ladder *apemost_single(mcmc *m) {
         cache->n_shards = 1;
         cache->lo[0] = 0;
         cache->lo[1] = 1;
-        cache->s[0] = create_sampler(m, model, 1, 0, SINGLE_LADDER_SPAN, default_device());
+        cache->s[0] = create_sampler(m, model, 1, 0, SINGLE_LADDER_SPAN, default_device(), 0);
         alloc_view(cache);
         cache_data = m->data;
     }

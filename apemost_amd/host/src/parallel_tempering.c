@@ -270,13 +270,16 @@ static void sink_open(sample_sink *k, mcmc **chains, unsigned int n_beta, unsign
         unsigned char header[64];
         uint32_t u32[4], u32b;
         uint64_t u64v = k->thin;
-        const int fresh = mode[0] == 'w' || fopen("samples.bin", "rb") == NULL;
+        FILE *probe = mode[0] == 'w' ? NULL : fopen("samples.bin", "rb");
+        const int fresh = probe == NULL;
         /* the chains the text sink would write parameter files for come first in the ladder */
         while (k->n_param_chains < n_beta && chains[k->n_param_chains]->files != NULL)
             k->n_param_chains++;
         if (k->binary == 2)
             k->n_param_chains = n_beta;
         u32b = k->n_param_chains;
+        if (probe != NULL)
+            fclose(probe);
         k->bin = open_or_die("samples.bin", fresh ? "wb" : "ab");
         if (fresh) {
             memset(header, 0, sizeof header);

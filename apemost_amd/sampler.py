@@ -102,6 +102,13 @@ class HipSampler:
         capi.check(self.L.apemost_hip_waves_per_chain(self._h, C.byref(w), C.byref(l)))
         return w.value, bool(l.value)
 
+    @property
+    def launch_policy(self):
+        """(one-barrier kernel, cooperative multi-round launches, rounds one launch may hold)"""
+        ob, co, mr = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        capi.check(self.L.apemost_hip_launch_policy(self._h, C.byref(ob), C.byref(co), C.byref(mr)))
+        return bool(ob.value), bool(co.value), mr.value
+
     def set_state(self, state, fields=None):
         v = state.view(fields) if fields else state.view()
         capi.check(self.L.apemost_hip_set_state(self._h, C.byref(v)))

@@ -113,7 +113,13 @@ enum {
     /* test hook: every cooperative launch is treated as refused by the runtime, so that the path a
      * real refusal takes (the launch re-issued round by round, single-round launches from then on)
      * can be exercised on a machine where the runtime never refuses */
-    APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE = 128
+    APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE = 128,
+    /* test hook for the other designed failure: inside a multi-round launch the lower chain of the
+     * pair of swap attempt 3 does not publish its record, and every bounded wait of the launch gives
+     * up after a few thousand polls instead of eight million -- the partner's wait runs out, the
+     * launch's error word is raised, apemost_hip_synchronize reports it, and the sampler issues one
+     * round per launch from then on */
+    APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH = 256
 };
 
 typedef struct {
@@ -192,6 +198,11 @@ int apemost_hip_synchronize(apemost_hip_sampler *s);
 /* the HIP stream (hipStream_t) every launch of this sampler goes to */
 int apemost_hip_stream(apemost_hip_sampler *s, void **stream);
 int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, int *data_in_lds);
+/* how this sampler's stepping launches are issued as things stand: the one-barrier kernel or the
+ * two-phase one, multi-round launches through hipLaunchCooperativeKernel or plain, and how many
+ * rounds one launch may hold (1: the grid is not resident, a cooperative launch was refused, or a
+ * hand-off timed out) */
+int apemost_hip_launch_policy(apemost_hip_sampler *s, int32_t *one_barrier, int32_t *cooperative, int32_t *max_rounds);
 /* move the shard along the ladder (single-chain API of the C host layer: the chain's ladder
  * position selects its RNG streams); offset + n_chains must stay <= n_chains_global */
 int apemost_hip_set_chain_offset(apemost_hip_sampler *s, int64_t chain_offset);

@@ -597,3 +597,95 @@ def test_circular_parameters_wrap_like_the_reference():
     orc.run_sampler(lad2, orc.Rng(orc.RNG_STREAMS, 8, lad2), 20, 10)
     assert not np.array_equal(lad2.params, lad.params)
     s.close()
+
+
+@pytest.mark.parametrize("flags", [0, capi.FLAG_RANDOMSWAP])
+def test_config4_shard_kernel_as_the_bench_launches_it_matches_oracle(flags):
+    """BASELINE config 4 as one GPU of eight sees it and as bench.py --config 4 launches it: pulse,
+    256 chains x 1024 points, the geometry the engine chooses by itself (eight likelihood waves + owner
+    + three producers per chain, the data vector in LDS), n_swap 1 -- every step is a round, so the
+    pipeline of prepared proposals runs through round boundaries that are none and restarts only for
+    the two chains of a swap attempt --, 256 rounds in ONE launch placed by hipLaunchCooperativeKernel
+    (256 twelve-wave workgroups fit the occupancy figure, one per CU, but not the engine's cautious
+    estimate), the pulse prior computed one logarithm per lane.  Against the oracle: counters, ticks
+    and swap counts bit-exact, every recorded row to 1e-9; the same under -DRANDOMSWAP."""
+    torch = _torch()
+    n_chain, n_rounds = 256, 256
+    w = wl.pulse(n_data=1024, n_chain=n_chain)
+    st, lad, rng = make_pair(w, n_chain, seed=404, init_prob=True)
+    lad.randomswap = 1 if flags & capi.FLAG_RANDOMSWAP else 0
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=404, flags=flags)
+    assert s.geometry == (8, True)
+    one_barrier, cooperative, max_rounds = s.launch_policy
+    assert one_barrier and cooperative and max_rounds >= n_rounds
+    s.set_state(st)
+    d = torch.zeros((n_rounds, 1, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
+    before = s.round[0]
+    s.launch_rounds(n_rounds, 1, False, d.data_ptr())          # one launch, as one bench step
+    s.launch_round(0, True)                                     # the swap attempt that closes the last round
+    s.synchronize()
+    assert s.launch_policy[1] and s.round[0] - before == n_rounds   # the runtime placed the grid; nothing was re-issued
+    dev = s.get_state()
+    ref = orc.run_sampler(lad, rng, n_rounds, 1, record=True, n_threads=8)
+    assert_match(dev, lad, rng, what="config-4 shard kernel flags=%d" % flags)
+    np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9, atol=1e-300)
+    assert dev.swapcount.sum() > 20 and np.all(dev.accept + dev.reject == n_rounds)
+    s.close()
+
+
+def test_a_hand_off_that_times_out_is_reported_and_the_sampler_falls_back():
+    """The safety net under multi-round launches: a workgroup that waits for its swap partner's record
+    gives up after a bounded number of polls (8 million; a few thousand under the test hook), raises
+    the launch's error word and goes on, so the grid always drains.  FLAG_TEST_WITHHOLD_PUBLISH makes
+    the lower chain of swap attempt 3 keep its publish to itself: synchronize reports code 1, the
+    word is cleared, the sampler holds one round per launch from then on, and -- reloaded -- gives
+    the oracle's chain."""
+    torch = _torch()
+    n_chain, n_rounds, n_swap = 32, 40, 3
+    w = wl.simplesin(n_data=128, n_chain=n_chain)
+    st, lad, rng = make_pair(w, n_chain, seed=91)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=91, flags=capi.FLAG_TEST_WITHHOLD_PUBLISH)
+    s.set_state(st)
+    assert s.max_rounds_per_launch > 1
+    assert s.swap_pair(3) >= 0
+    s.launch_rounds(n_rounds, n_swap, False)
+    with pytest.raises(capi.ApemostHipError) as err:
+        s.synchronize()
+    assert "code 1" in str(err.value) and "one round per launch" in str(err.value)
+    s.synchronize()                                    # the word is cleared: no second report
+    assert s.max_rounds_per_launch == 1 and s.launch_policy == (s.launch_policy[0], False, 1)
+    with pytest.raises(capi.ApemostHipError):
+        s.launch_rounds(2, n_swap, True)               # refused on the host, nothing launched
+    # the results of the void launch are dropped: reload, rewind the swap stream, run again
+    s.set_state(st)
+    s.set_round(0, False)
+    d = torch.zeros((n_rounds, n_swap, n_chain, 6), dtype=torch.float64, device="cuda")
+    s.run_sampler(n_rounds, n_swap, d.data_ptr())
+    s.synchronize()
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    assert_match(s.get_state(), lad, rng, what="after a hand-off timeout")
+    np.testing.assert_allclose(d.cpu().numpy().reshape(ref.shape), ref, rtol=1e-9)
+    s.close()
+
+
+def test_a_refused_cooperative_launch_in_the_middle_of_a_sharded_run():
+    """ShardedLadder.run_sampler asks for the launch limit before every launch (it was read
+    once, so after a refusal -- the engine falls to one round per launch -- the next launch of the
+    same call asked for more and was rejected).  1100 rounds is more than one launch holds: the first
+    launch is refused and re-issued round by round, all later ones are single rounds."""
+    torch = _torch()
+    from apemost_amd.distributed import HipShardEngine, ShardedLadder
+    n_chain, n_rounds, n_swap = 16, 1100, 2
+    w = wl.simplesin(n_data=64, n_chain=n_chain)
+    st, lad, rng = make_pair(w, n_chain, seed=5150)
+    s = HipSampler(w.model, 4, n_chain, w.data, seed=5150,
+                   flags=capi.FLAG_COOPERATIVE_LAUNCH | capi.FLAG_TEST_REFUSE_COOPERATIVE)
+    s.set_state(st)
+    assert s.max_rounds_per_launch == 1024
+    ladder = ShardedLadder(HipShardEngine(s, torch), n_chain, 0, n_chain, 0, 1, None)
+    ladder.run_sampler(n_rounds, n_swap, None)
+    s.synchronize()
+    assert s.max_rounds_per_launch == 1
+    orc.run_sampler(lad, rng, n_rounds, n_swap, n_threads=8)
+    assert_match(s.get_state(), lad, rng, what="refusal mid-run")
+    s.close()
