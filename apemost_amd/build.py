@@ -20,7 +20,7 @@ def _stale(target, sources):
 
 
 OBJ = os.path.join(CSRC, "obj")
-N_MODEL_TUS = 8   # models 0-3 and their variant instantiations 4-7 (pt_device.h kVariantModel)
+MODEL_TUS = (0, 1, 2, 3, 8, 9, 10, 11)   # the built-in models and their variant instantiations (pt_device.h kVariantModel)
 
 
 def _sources():
@@ -42,7 +42,7 @@ def build_hip(force=False, verbose=False):
     if force or _stale(abi_obj, [abi_src] + headers):
         jobs.append([HIPCC] + compile_flags + ["-o", abi_obj, abi_src])
     objs = [abi_obj]
-    for k in range(N_MODEL_TUS):
+    for k in MODEL_TUS:
         obj = os.path.join(OBJ, "model_%d.o" % k)
         objs.append(obj)
         if force or _stale(obj, [model_src] + headers):
@@ -58,7 +58,7 @@ def build_hip(force=False, verbose=False):
         with ThreadPoolExecutor(workers) as pool:
             list(pool.map(run, jobs))
     if jobs or force or _stale(HIP_LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"])
     return HIP_LIB
 
 

@@ -34,7 +34,8 @@ class Config(C.Structure):
                 ("n_cols", C.c_int32), ("waves_per_chain", C.c_int32), ("lds_policy", C.c_int32),
                 ("flags", C.c_int32), ("chain_offset", C.c_int64),
                 ("n_chains_global", C.c_int64), ("seed", C.c_uint64), ("sigma", C.c_double),
-                ("hmin", C.c_double), ("circular_params", C.c_uint64), ("adapt_target", C.c_double)]
+                ("hmin", C.c_double), ("circular_params", C.c_uint64), ("adapt_target", C.c_double),
+                ("device_model_source", C.c_char_p)]
 
 
 class StateView(C.Structure):

@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+
 #include <chrono>
 #include <string>
 #include <thread>
@@ -112,10 +115,10 @@ APEMOST_EXTERN_MODEL(0)
 APEMOST_EXTERN_MODEL(1)
 APEMOST_EXTERN_MODEL(2)
 APEMOST_EXTERN_MODEL(3)
-APEMOST_EXTERN_MODEL(4)
-APEMOST_EXTERN_MODEL(5)
-APEMOST_EXTERN_MODEL(6)
-APEMOST_EXTERN_MODEL(7)
+APEMOST_EXTERN_MODEL(8)
+APEMOST_EXTERN_MODEL(9)
+APEMOST_EXTERN_MODEL(10)
+APEMOST_EXTERN_MODEL(11)
 
 static hipError_t dispatch_any(int model, int waves, const AnyOp &op) {
     switch (model) {
@@ -127,16 +130,16 @@ static hipError_t dispatch_any(int model, int waves, const AnyOp &op) {
         return model_dispatch<2>(waves, op);
     case 3:
         return model_dispatch<3>(waves, op);
-    case 4:
-        return model_dispatch<4>(waves, op);
-    case 5:
-        return model_dispatch<5>(waves, op);
-    case 6:
-        return model_dispatch<6>(waves, op);
-    case 7:
-        return model_dispatch<7>(waves, op);
+    case 8:
+        return model_dispatch<8>(waves, op);
+    case 9:
+        return model_dispatch<9>(waves, op);
+    case 10:
+        return model_dispatch<10>(waves, op);
+    case 11:
+        return model_dispatch<11>(waves, op);
     }
-    return hipErrorInvalidDeviceFunction;
+    return hipErrorInvalidDeviceFunction; // (APEMOST_MODEL_USER never comes here: its kernels are a run-time module)
 }
 static hipError_t dispatch(int model, int waves, const LaunchOp &f) {
     AnyOp op;
@@ -217,6 +220,11 @@ struct apemost_hip_sampler {
         u64 segments, launches_by_waves[9];
     } cal;
     unsigned big_lds_set; // bit w: the LDS opt-in of the w-wave kernels has been made
+    // APEMOST_MODEL_USER: the kernels of the user's likelihood, compiled by hiprtc at create time
+    struct {
+        hipModule_t module;
+        hipFunction_t round, calibrate, calc_model, loglike;
+    } user;
     double *edge_out, *edge_in;  // edge records for in-process shard exchanges (created on first use)
     hipEvent_t ev_exported, ev_imported;
     hipStream_t copy_stream; // drains sample rows while the next launch runs (created on first use)
@@ -271,6 +279,7 @@ extern "C" int apemost_hip_device_info(int device, char *name, size_t name_len, 
 
 static int enable_big_lds(apemost_hip_sampler *s, int waves);
 static int max_rounds_per_launch(apemost_hip_sampler *s);
+static int user_model_build(apemost_hip_sampler *s);
 template <bool LDS>
 static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks);
 static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data);
@@ -344,6 +353,8 @@ static void release(apemost_hip_sampler *s) {
         hipHostFree(s->cal.h_list);
     if (s->cal.ev)
         hipEventDestroy(s->cal.ev);
+    if (s->user.module)
+        hipModuleUnload(s->user.module);
     if (s->copy_stream) {
         hipStreamSynchronize(s->copy_stream);
         hipStreamDestroy(s->copy_stream);
@@ -365,6 +376,138 @@ static void release(apemost_hip_sampler *s) {
     delete s;
 }
 
+// ---- APEMOST_MODEL_USER: the user's likelihood compiled into the one-wave kernels at run time ----
+// hiprtc is loaded on demand (a sampler of a built-in model never needs it).  The translation unit is
+// "#include pt_kernels.h" -- the same kernel templates this library was built from -- followed by the
+// user's file, which defines the two functions Model<APEMOST_MODEL_USER> calls; the four kernels a
+// one-wave sampler launches are named as template instantiations and fetched by their lowered names.
+namespace {
+struct HipRtc {
+    void *lib;
+    hiprtcResult (*create)(hiprtcProgram *, const char *, const char *, int, const char **, const char **);
+    hiprtcResult (*destroy)(hiprtcProgram *);
+    hiprtcResult (*add_name)(hiprtcProgram, const char *);
+    hiprtcResult (*compile)(hiprtcProgram, int, const char **);
+    hiprtcResult (*log_size)(hiprtcProgram, size_t *);
+    hiprtcResult (*log)(hiprtcProgram, char *);
+    hiprtcResult (*lowered)(hiprtcProgram, const char *, const char **);
+    hiprtcResult (*code_size)(hiprtcProgram, size_t *);
+    hiprtcResult (*code)(hiprtcProgram, char *);
+};
+} // namespace
+
+static int hiprtc_load(HipRtc &r) {
+    static HipRtc cached = {};
+    if (!cached.lib) {
+        const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+        for (const char *n : names)
+            if ((cached.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+                break;
+        if (!cached.lib)
+            return fail(APEMOST_HIP_ERR_UNSUPPORTED, "a user-supplied device model needs libhiprtc.so: %s", dlerror());
+        bool ok = true;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(cached.lib, n);
+            ok = ok && p;
+            return p;
+        };
+        cached.create = (decltype(cached.create))sym("hiprtcCreateProgram");
+        cached.destroy = (decltype(cached.destroy))sym("hiprtcDestroyProgram");
+        cached.add_name = (decltype(cached.add_name))sym("hiprtcAddNameExpression");
+        cached.compile = (decltype(cached.compile))sym("hiprtcCompileProgram");
+        cached.log_size = (decltype(cached.log_size))sym("hiprtcGetProgramLogSize");
+        cached.log = (decltype(cached.log))sym("hiprtcGetProgramLog");
+        cached.lowered = (decltype(cached.lowered))sym("hiprtcGetLoweredName");
+        cached.code_size = (decltype(cached.code_size))sym("hiprtcGetCodeSize");
+        cached.code = (decltype(cached.code))sym("hiprtcGetCode");
+        if (!ok) {
+            cached.lib = nullptr;
+            return fail(APEMOST_HIP_ERR_UNSUPPORTED, "libhiprtc.so lacks an expected entry point");
+        }
+    }
+    r = cached;
+    return APEMOST_HIP_OK;
+}
+
+// where this library's kernel headers are: csrc/ beside the .so, include/ one level up (in-tree
+// layout), or APEMOST_HIP_SOURCE_DIR / APEMOST_HIP_INCLUDE_DIR
+static void source_dirs(std::string &csrc, std::string &inc) {
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr((const void *)&apemost_hip_abi_version, &info) && info.dli_fname) {
+        dir = info.dli_fname;
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+    }
+    const char *e1 = getenv("APEMOST_HIP_SOURCE_DIR"), *e2 = getenv("APEMOST_HIP_INCLUDE_DIR");
+    csrc = e1 ? e1 : dir + "/csrc";
+    inc = e2 ? e2 : dir + "/../include";
+}
+
+static int user_model_build(apemost_hip_sampler *s) {
+    HipRtc rtc;
+    int rc = hiprtc_load(rtc);
+    if (rc)
+        return rc;
+    FILE *f = fopen(s->cfg.device_model_source, "rb");
+    if (!f)
+        return fail(APEMOST_HIP_ERR_INVALID, "device model source %s: cannot be read", s->cfg.device_model_source);
+    std::string user;
+    char buf[4096];
+    for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;)
+        user.append(buf, n);
+    fclose(f);
+    std::string csrc, inc;
+    source_dirs(csrc, inc);
+    const std::string src = "#define APEMOST_USER_MODEL 1\n#include \"pt_kernels.h\"\n#line 1 \"" +
+                            std::string(s->cfg.device_model_source) + "\"\n" + user + "\n";
+    hiprtcProgram prog = nullptr;
+    if (rtc.create(&prog, src.c_str(), "apemost_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(APEMOST_HIP_ERR_RUNTIME, "hiprtcCreateProgram failed");
+    char names[4][128];
+    const int km = s->kmodel, base = APEMOST_MODEL_USER;
+    snprintf(names[0], sizeof names[0], "apemost::pt_round_kernel<%d, 1, false, false>", km);
+    snprintf(names[1], sizeof names[1], "apemost::pt_calibrate_kernel<%d, 1, false, false>", km);
+    snprintf(names[2], sizeof names[2], "apemost::pt_calc_model_kernel<%d, 1, false>", base);
+    snprintf(names[3], sizeof names[3], "apemost::pt_loglike_kernel<%d, 1, false>", base);
+    for (auto &n : names)
+        rtc.add_name(prog, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->cfg.device));
+    const std::string arch = std::string("--offload-arch=") + prop.gcnArchName, i1 = "-I" + csrc, i2 = "-I" + inc;
+    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", i1.c_str(), i2.c_str(), "-I/opt/rocm/include"};
+    const hiprtcResult cr = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        rtc.log_size(prog, &n);
+        std::string log(n + 1, 0);
+        if (n)
+            rtc.log(prog, &log[0]);
+        rtc.destroy(&prog);
+        return fail(APEMOST_HIP_ERR_INVALID, "device model %s does not compile:\n%.400s", s->cfg.device_model_source, log.c_str());
+    }
+    size_t code_bytes = 0;
+    rtc.code_size(prog, &code_bytes);
+    std::vector<char> code(code_bytes);
+    rtc.code(prog, code.data());
+    std::string lowered[4];
+    for (int i = 0; i < 4; i++) {
+        const char *low = nullptr;
+        if (rtc.lowered(prog, names[i], &low) != HIPRTC_SUCCESS || !low) {
+            rtc.destroy(&prog);
+            return fail(APEMOST_HIP_ERR_RUNTIME, "hiprtcGetLoweredName(%s) failed", names[i]);
+        }
+        lowered[i] = low;
+    }
+    rtc.destroy(&prog);
+    HIP_TRY(hipModuleLoadData(&s->user.module, code.data()));
+    HIP_TRY(hipModuleGetFunction(&s->user.round, s->user.module, lowered[0].c_str()));
+    HIP_TRY(hipModuleGetFunction(&s->user.calibrate, s->user.module, lowered[1].c_str()));
+    HIP_TRY(hipModuleGetFunction(&s->user.calc_model, s->user.module, lowered[2].c_str()));
+    HIP_TRY(hipModuleGetFunction(&s->user.loglike, s->user.module, lowered[3].c_str()));
+    return APEMOST_HIP_OK;
+}
+
 // the part of apemost_hip_create that can fail after the sampler object exists
 static int create_body(apemost_hip_sampler *s) {
     const apemost_hip_config *cfg = &s->cfg;
@@ -376,7 +519,7 @@ static int create_body(apemost_hip_sampler *s) {
     const size_t fixed_lds = (kFixedLdsDoubles + (size_t)cand_slots(s->waves) * 2 * kWave) * sizeof(double);
     const size_t data_lds = (size_t)2 * cfg->n_data * sizeof(double);
     const size_t fixed_max = fixed_lds > kObFixedDoubles * sizeof(double) ? fixed_lds : kObFixedDoubles * sizeof(double);
-    s->lds_data = fixed_max + data_lds <= 160 * 1024 - 1024 && cfg->lds_policy != 2 &&
+    s->lds_data = fixed_max + data_lds <= 160 * 1024 - 1024 && cfg->lds_policy != 2 && cfg->model != APEMOST_MODEL_USER &&
                   (cfg->lds_policy == 1 || choose_lds(*cfg, fixed_lds + data_lds));
     s->lds_bytes = fixed_lds + (s->lds_data ? data_lds : 0);
     s->lds_fixed_bytes = fixed_lds;
@@ -407,6 +550,7 @@ static int create_body(apemost_hip_sampler *s) {
     if (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM)
         s->sh.circular |= (u64)kProposalFlat << kProposalShift;
     s->sh.variant = (cfg->flags & APEMOST_HIP_FLAG_RANDOMSWAP) ? kVariantRandomSwap : 0;
+    s->sh.variant |= (int)((unsigned)cfg->n_cols << 16);
     if (cfg->flags & APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH)
         s->sh.variant |= kVariantTestWithhold;
     s->kmodel = cfg->model + ((cfg->flags & (APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC | APEMOST_HIP_FLAG_PROPOSAL_UNIFORM |
@@ -415,6 +559,8 @@ static int create_body(apemost_hip_sampler *s) {
                                   : 0);
     s->sh.x_abs_max = INFINITY; // until set_data
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (cfg->model == APEMOST_MODEL_USER && (rc = user_model_build(s)))
+        return rc;
     if ((rc = enable_big_lds(s, s->waves)))
         return rc;
     {
@@ -427,11 +573,15 @@ static int create_body(apemost_hip_sampler *s) {
         // variant exists (8 likelihood waves per chain), the classic two-phase step otherwise
         s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
         int b_lds = 0, b_plain = 0;
+        if (s->user.module) {
+            HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&b_plain, s->user.round, kWave, s->lds_fixed_bytes));
+        } else {
         if (s->lds_data)
             HIP_TRY(round_occupancy<true>(s->kmodel, s->waves, s->producers, s->one_barrier,
                                           s->one_barrier ? ob_lds_bytes(s, true) : s->lds_bytes, &b_lds));
         HIP_TRY(round_occupancy<false>(s->kmodel, s->waves, s->producers, s->one_barrier,
                                        s->one_barrier ? ob_lds_bytes(s, false) : s->lds_fixed_bytes, &b_plain));
+        }
         const long long cus = prop.multiProcessorCount;
         s->resident_lds = s->lds_data && (long long)cfg->n_chains <= (long long)(b_lds - 1) * cus;
         s->resident_plain = (long long)cfg->n_chains <= (long long)(b_plain - 1) * cus;
@@ -478,6 +628,8 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     if (cfg->n_chains < 1 || cfg->n_data < 1 || cfg->n_cols < 2)
         return fail(APEMOST_HIP_ERR_INVALID, "n_chains %d, n_data %d, n_cols %d invalid", cfg->n_chains,
                     cfg->n_data, cfg->n_cols);
+    if (cfg->n_cols > 65535)
+        return fail(APEMOST_HIP_ERR_INVALID, "n_cols %d: at most 65535 data columns", cfg->n_cols);
     if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->n_chains > cfg->n_chains_global)
         return fail(APEMOST_HIP_ERR_INVALID, "shard [%lld,%lld) outside ladder of %lld chains",
                     (long long)cfg->chain_offset, (long long)(cfg->chain_offset + cfg->n_chains),
@@ -512,9 +664,17 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
         if (cfg->n_par != 7)
             return fail(APEMOST_HIP_ERR_INVALID, "pulse_vrot needs n_par = 7");
         break;
+    case APEMOST_MODEL_USER:
+        if (!cfg->device_model_source || !*cfg->device_model_source)
+            return fail(APEMOST_HIP_ERR_INVALID, "APEMOST_MODEL_USER needs device_model_source (include/apemost_device_model.h)");
+        if (cfg->waves_per_chain > 1 || cfg->lds_policy == 1)
+            return fail(APEMOST_HIP_ERR_INVALID, "a user-supplied model runs in the one-wave kernels and reads the data rows by index");
+        break;
     default:
         return fail(APEMOST_HIP_ERR_UNSUPPORTED, "unknown device model %d", cfg->model);
     }
+    if (cfg->model != APEMOST_MODEL_USER && cfg->device_model_source)
+        return fail(APEMOST_HIP_ERR_INVALID, "device_model_source is for APEMOST_MODEL_USER only");
     int rc = apemost_hip_device_info(cfg->device, nullptr, 0, nullptr, nullptr);
     if (rc != APEMOST_HIP_OK)
         return rc;
@@ -528,6 +688,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->launches = 0;
     s->launches_at_begin = 0;
     memset(&s->cal, 0, sizeof s->cal);
+    memset(&s->user, 0, sizeof s->user);
     s->big_lds_set = 0;
     s->stream = nullptr;
     s->ev0 = s->ev1 = nullptr;
@@ -537,7 +698,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->ev_exported = s->ev_imported = nullptr;
     s->h_word = nullptr;
     s->handoff_failed = false;
-    s->waves = choose_waves(*cfg);
+    s->waves = cfg->model == APEMOST_MODEL_USER ? 1 : choose_waves(*cfg);
     if (s->waves == 6 && (cfg->flags & (APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC | APEMOST_HIP_FLAG_PROPOSAL_UNIFORM |
                                         APEMOST_HIP_FLAG_RANDOMSWAP))) {
         delete s;
@@ -770,6 +931,18 @@ static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const
     op.args = args;
     if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
         return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: cooperative launch refused (test hook)");
+    if (s->user.module) {
+        // the kernels of a user-supplied model live in a run-time module: one wave per chain, data through L2
+        hipFunction_t f = kind == K_ROUND ? s->user.round : kind == K_CALIB ? s->user.calibrate
+                          : kind == K_CALC ? s->user.calc_model : kind == K_EVAL ? s->user.loglike : nullptr;
+        if (!f || waves != 1 || lds_data || coop)
+            return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: no such kernel for a user-supplied model");
+        void *params[] = {const_cast<void *>(args)};
+        const hipError_t e = hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, kWave, 1, 1, (unsigned)op.lds, s->stream, params, nullptr);
+        if (e != hipSuccess)
+            return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+        return APEMOST_HIP_OK;
+    }
     const hipError_t err = dispatch(s->kmodel, waves, op);
     if (err != hipSuccess)
         return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(err));
@@ -858,7 +1031,7 @@ static hipError_t round_occupancy(int model, int waves, bool producers, bool one
 // shape that may stage the data vector, each with its own footprint (the one-barrier kernels carve
 // 1 KiB more than the two-phase ones).  Made once per shape, before its first launch.
 static int enable_big_lds(apemost_hip_sampler *s, int waves) {
-    if ((s->big_lds_set >> waves) & 1)
+    if (((s->big_lds_set >> waves) & 1) || s->user.module)
         return APEMOST_HIP_OK;
     LdsAttrOp op;
     op.bytes = classic_lds_bytes(s, waves, true);
@@ -1288,12 +1461,12 @@ static CalibShape calib_shape(const apemost_hip_sampler *s, int n_active) {
     CalibShape g;
     apemost_hip_config c = s->cfg;
     c.n_chains = n_active;
-    g.waves = choose_waves(c);
-    if (!built(s->kmodel, g.waves))
+    g.waves = s->user.module ? 1 : choose_waves(c);
+    if (!s->user.module && !built(s->kmodel, g.waves))
         g.waves = s->waves; // (development builds hold only some shapes)
     g.one_barrier = has_one_barrier(g.waves) && s->kmodel < kVariantModel && !(s->cfg.flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
     const size_t bytes = g.one_barrier ? ob_lds_bytes(s, true) : classic_lds_bytes(s, g.waves, true);
-    g.lds_data = bytes <= 160 * 1024 - 1024 && c.lds_policy != 2 && (c.lds_policy == 1 || choose_lds(c, bytes));
+    g.lds_data = !s->user.module && bytes <= 160 * 1024 - 1024 && c.lds_policy != 2 && (c.lds_policy == 1 || choose_lds(c, bytes));
     // A segment of about a quarter of a second: likelihood evaluations a chain gets through in that
     // time, from a coarse model of one evaluation (1.7 ns per data point and wavefront, 0.7 us at
     // least, stretched when the wavefronts outnumber the SIMDs).  Always whole blocks, at least one.
@@ -1697,9 +1870,9 @@ template hipError_t model_dispatch<0>(int, const AnyOp &);
 template hipError_t model_dispatch<1>(int, const AnyOp &);
 template hipError_t model_dispatch<2>(int, const AnyOp &);
 template hipError_t model_dispatch<3>(int, const AnyOp &);
-template hipError_t model_dispatch<4>(int, const AnyOp &);
-template hipError_t model_dispatch<5>(int, const AnyOp &);
-template hipError_t model_dispatch<6>(int, const AnyOp &);
-template hipError_t model_dispatch<7>(int, const AnyOp &);
+template hipError_t model_dispatch<8>(int, const AnyOp &);
+template hipError_t model_dispatch<9>(int, const AnyOp &);
+template hipError_t model_dispatch<10>(int, const AnyOp &);
+template hipError_t model_dispatch<11>(int, const AnyOp &);
 } // namespace apemost
 #endif

@@ -75,6 +75,8 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PROD
     e.setup_lanes();
     if (threadIdx.x == 0)
         *e.fail_flag() = 0; // ordered before its first use by the barrier every kernel has after setup
+    if constexpr (Model<MODEL % kVariantModel>::kIndexed)
+        e.m.set_data(d.data, sh.n_data, (int)((unsigned)sh.variant >> 16));
     if (d.f != nullptr) // a resident chain: its prior box may make the per-step argument check void
         e.m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
     if (LDS_DATA) {
@@ -1052,6 +1054,7 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
     }
 }
 
+#ifndef __HIPCC_RTC__ // (a run-time compilation of a user-supplied model holds the kernels only)
 // ---- launch dispatch over (model, waves, lds) ----
 enum KernelKind { K_ROUND, K_ROUND_OB, K_CALC, K_EVAL, K_CALIB, K_CALIB_OB };
 
@@ -1258,5 +1261,7 @@ hipError_t model_dispatch(int waves, const AnyOp &op) {
     }
     return hipErrorInvalidValue;
 }
+
+#endif // __HIPCC_RTC__
 
 } // namespace apemost

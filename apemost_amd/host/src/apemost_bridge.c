@@ -181,6 +181,7 @@ static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned in
     (void)run_ladder;
 #endif
     cfg.adapt_target = TARGET_ACCEPTANCE_RATE;
+    cfg.device_model_source = model == APEMOST_MODEL_USER ? getenv("APEMOST_DEVICE_MODEL_SRC") : NULL;
     apemost_hip_or_die(apemost_hip_create(&cfg, &s), "apemost_hip_create");
     if (m->data->tda != m->data->size2) {
         fprintf(stderr, "data matrix must be contiguous\n");
@@ -200,18 +201,23 @@ static int model_fits(int model, unsigned int n_par) {
         return n_par >= 4 && (n_par - 2) % 2 == 0;
     case APEMOST_MODEL_PULSE_VROT:
         return n_par == 7;
+    case APEMOST_MODEL_USER:
+        return getenv("APEMOST_DEVICE_MODEL_SRC") != NULL;
     }
     return 0;
 }
 
 static const char *model_name(int model) {
-    static const char *names[] = {"simplesin", "pulse", "pulse_vrot", "sine3"};
-    return (model >= 0 && model < 4) ? names[model] : "?";
+    static const char *names[] = {"simplesin", "pulse", "pulse_vrot", "sine3", "user"};
+    return (model >= 0 && model < 5) ? names[model] : "?";
 }
 
 /* The user's likelihood is host C and cannot run on the GPU; the engine carries device
- * re-implementations of the BASELINE models.  Find the one that reproduces the linked
- * calc_model() at a handful of points inside the prior box, or stop. */
+ * re-implementations of the BASELINE models, and takes any other likelihood as device source
+ * (APEMOST_DEVICE_MODEL_SRC=<file>, include/apemost_device_model.h; examples/device_models/ has the
+ * reference's apps/simplesin2.c, normal.c and bernoulli_example.c).  Find the device likelihood that
+ * reproduces the linked calc_model() -- or the functions registered with set_function -- at a
+ * handful of points inside the prior box, or stop: a device model is never taken on trust. */
 #define DETECT_POINTS 6
 int apemost_detect_model(mcmc *m) {
     static int cached = -1;
@@ -259,11 +265,13 @@ int apemost_detect_model(mcmc *m) {
     m->prob = saved_prob;
     m->prior = saved_prior;
 
-    for (model = 0; model < 4 && found < 0; model++) {
+    for (model = 0; model < 5 && found < 0; model++) {
         apemost_hip_sampler *s;
         int ok = 1;
         if (!model_fits(model, n))
             continue;
+        if (getenv("APEMOST_DEVICE_MODEL_SRC") != NULL && model != APEMOST_MODEL_USER)
+            continue; /* the user names the device likelihood: that one is checked, no other */
         if (forced && strcmp(forced, model_name(model)) != 0)
             continue;
         s = create_sampler(m, model, 1, 0, 1, default_device(), 0);
@@ -274,7 +282,7 @@ int apemost_detect_model(mcmc *m) {
             const double scale = fabs(host_prob[j]) > 1 ? fabs(host_prob[j]) : 1;
             if (!(fabs(dev_prob[j] - host_prob[j]) <= 1e-9 * scale))
                 ok = 0;
-            if (model == APEMOST_MODEL_PULSE || model == APEMOST_MODEL_PULSE_VROT)
+            if (model == APEMOST_MODEL_PULSE || model == APEMOST_MODEL_PULSE_VROT || model == APEMOST_MODEL_USER)
                 if (!(fabs(dev_prior[j] - host_prior[j]) <= 1e-9 * (fabs(host_prior[j]) + 1)))
                     ok = 0;
         }
@@ -285,10 +293,13 @@ int apemost_detect_model(mcmc *m) {
     free(beta);
     if (found < 0) {
         fprintf(stderr,
-                "APEMoST MI355X engine: the linked calc_model() (%u parameters) matches none of the device\n"
-                "likelihoods (simplesin, pulse, pulse_vrot, sine3; SIGMA=%g HMIN=%g).  Device models must\n"
-                "reproduce the host plugin to 1e-9; refusing to sample a different posterior.\n",
-                n, (double)SIGMA, (double)HMIN);
+                "APEMoST MI355X engine: the linked calc_model() (%u parameters) matches %s\n"
+                "(SIGMA=%g HMIN=%g).  Device models must reproduce the host plugin to 1e-9; refusing to sample a\n"
+                "different posterior.  A likelihood other than the built-in ones is given as device source:\n"
+                "APEMOST_DEVICE_MODEL_SRC=<file> (include/apemost_device_model.h).\n",
+                n, getenv("APEMOST_DEVICE_MODEL_SRC") ? "not the device model of APEMOST_DEVICE_MODEL_SRC"
+                                                      : "none of the device likelihoods (simplesin, pulse, pulse_vrot, sine3)",
+                (double)SIGMA, (double)HMIN);
         exit(1);
     }
     IFDEBUG printf("device likelihood: %s\n", model_name(found));

@@ -57,7 +57,7 @@ def calc_beta_0(state, chain, stepwidth_factors):
 class HipSampler:
     def __init__(self, model, n_par, n_chains, data, seed=0, device=0, chain_offset=0,
                  n_chains_global=None, waves_per_chain=0, sigma=0.5, hmin=1e-6, lds_policy=0, circular_params=0,
-                 flags=0, adapt_target=0.0):
+                 flags=0, adapt_target=0.0, device_model_source=None):
         data = np.ascontiguousarray(data, dtype=np.float64)
         assert data.ndim == 2
         self.cfg = capi.Config(abi_version=capi.ABI_VERSION, device=device, model=model, n_par=n_par,
@@ -65,7 +65,8 @@ class HipSampler:
                                waves_per_chain=waves_per_chain, lds_policy=lds_policy, chain_offset=chain_offset,
                                n_chains_global=n_chains if n_chains_global is None else n_chains_global,
                                seed=seed, sigma=sigma, hmin=hmin, circular_params=circular_params, flags=flags,
-                               adapt_target=adapt_target)
+                               adapt_target=adapt_target,
+                               device_model_source=None if device_model_source is None else str(device_model_source).encode())
         self._h = C.c_void_p()
         self.L = capi.lib()
         capi.check(self.L.apemost_hip_create(C.byref(self.cfg), C.byref(self._h)))

@@ -8,6 +8,7 @@ file conventions: a `params` table of (start, min, max, name, step) rows
 import numpy as np
 
 MODEL_SIMPLESIN, MODEL_PULSE, MODEL_PULSE_VROT, MODEL_SINE3 = 0, 1, 2, 3
+MODEL_USER = 4   # device source supplied by the user (include/apemost_device_model.h)
 MODEL_NAMES = {0: "simplesin", 1: "pulse", 2: "pulse_vrot", 3: "sine3"}
 
 

@@ -2,9 +2,10 @@
 """bench.py -- Metropolis steps/s (all chains) of the parallel-tempering hot path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
-rank per GPU over RCCL).  One bench "step" = one pass of the hot path over one batch:
-ROUNDS_PER_STEP rounds of {n_swap Metropolis steps per chain + one swap attempt}
-(run_sampler's loop body, src/parallel_tempering.c:392-409), sample rows written to HBM.
+rank per GPU over RCCL).  One bench "step" = one pass of the hot path over one batch of synthetic
+work: LAUNCHES_PER_STEP launches of ROUNDS_PER_STEP rounds of {n_swap Metropolis steps per chain + one
+swap attempt} (run_sampler's loop body, src/parallel_tempering.c:392-409), sample rows written to HBM
+(20 steps are about a second of GPU time).
 Workload at every N: BASELINE config 2 per GPU -- simplesin, 128 chains x 1024 data points per
 GPU (weak scaling: the ladder has 128*N chains, block-partitioned over the ranks).
 `--config 3|4|5` selects the other GPU configs of BASELINE.json (per-GPU share of the ladder,
@@ -31,11 +32,14 @@ FP64_VALU_PEAK_TF = 78.6  # fp64 vector peak
 # rounds_per_step: rounds of one bench step = of one launch where the ladder is resident (the C host
 # launches up to apemost_hip_max_rounds_per_launch rounds at a time, bounded by its sample buffers):
 # chosen so that a launch is ~1 ms of work and its fixed cost (launch, staging, pipeline start) is small
+# launches_per_step: a bench step is that many such batches back to back, so that 20 steps are about a
+# second of GPU time (the driver's utilisation sampling and its own clock then see the kernel; the
+# timed region of round 2 was 25 ms)
 CONFIGS = {
-    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000, rounds_per_step=128),
-    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000, rounds_per_step=32),
-    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000, rounds_per_step=256),  # 2048 / 8 GPUs
-    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600, rounds_per_step=32),  # 16384 / 8 GPUs
+    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000, rounds_per_step=128, launches_per_step=40),
+    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000, rounds_per_step=32, launches_per_step=64),
+    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000, rounds_per_step=256, launches_per_step=120),  # 2048 / 8 GPUs
+    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600, rounds_per_step=32, launches_per_step=6),  # 16384 / 8 GPUs
 }
 
 
@@ -52,12 +56,18 @@ def parse():
     ap.add_argument("--burn-in", type=int, default=None, help="BURN_IN_ITERATIONS of the device calibration")
     ap.add_argument("--flags", type=int, default=0, help="apemost_hip_config.flags")
     ap.add_argument("--rounds-per-step", type=int, default=None)
+    ap.add_argument("--launches-per-step", type=int, default=None, help="batches of rounds-per-step rounds in one bench step")
+    ap.add_argument("--n-swap-rule", default="per_gpu_ladder", choices=["per_gpu_ladder", "reference"],
+                    help="--n-swap 0: 2000 / chains per GPU (the per-GPU work stays what it is at one GPU: weak "
+                         "scaling), or the reference's 2000 / n_beta of the whole ladder (src/parallel_tempering.c:228-231)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--lds", type=int, default=0, help="0 choose, 1 stage the data vector in LDS, 2 read it through L2")
     ap.add_argument("--no-samples", action="store_true", help="do not write per-step sample rows")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the device calibration before the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 = skip")
     ap.add_argument("--calib-dump", default=None, help="write the calibration's per-chain status and sweep counts (JSON)")
+    ap.add_argument("--maps-dump", default=None, help="debug: write /proc/self/maps there before exiting (to assign the "
+                                                      "addresses of a native stack trace to libraries)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even with one rank")
     a = ap.parse_args()
     for k, v in CONFIGS[a.config].items():
@@ -155,9 +165,10 @@ def main():
     n_global = n_local * world
     lo = rank * n_local
     w = wl.by_name(a.workload, n_data=a.n_data, n_chain=n_global)
-    n_swap = a.n_swap or max(1, 2000 // n_local)
+    n_swap = a.n_swap or max(1, 2000 // (n_local if a.n_swap_rule == "per_gpu_ladder" else n_global))
 
     R = a.rounds_per_step
+    LPS = a.launches_per_step
 
     # a calibrated-looking ladder: chebyshev betas, steps = steps0 * beta^-1/2
     st = LadderState.from_params(n_local, w.start, w.pmin, w.pmax, w.step * 0.3)
@@ -200,8 +211,9 @@ def main():
     ladder.prime()
 
     def one_step():
-        # the swap attempt that closes a bench step is applied at the start of the next one
-        ladder.run_sampler(R, n_swap, samples, finalize=False)
+        # the swap attempt that closes a batch is applied at the start of the next one
+        for _ in range(LPS):
+            ladder.run_sampler(R, n_swap, samples, finalize=False)
 
     def sync_all():
         s.synchronize()
@@ -221,23 +233,29 @@ def main():
     import ctypes as C
     ev_ms, launches = C.c_float(0), C.c_uint64(0)
     capi.check(s.L.apemost_hip_timer_end(s._h, C.byref(ev_ms), C.byref(launches)))
+    dt_rank = time.perf_counter() - t0   # this rank's own K steps, before it waits for the others
     sync_all()
     dt = time.perf_counter() - t0
+    per_rank = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([dt_rank, float(ladder.exchanges)], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank = np.array([e.cpu().numpy() for e in every])
 
     acc1 = s.get_state()
     d_acc = (acc1.accept - acc0.accept).astype(np.float64)
     d_rej = (acc1.reject - acc0.reject).astype(np.float64)
     acceptance = float(np.mean(d_acc / np.maximum(d_acc + d_rej, 1)))
-    total_steps = a.steps * R * n_swap * n_global
+    total_steps = a.steps * LPS * R * n_swap * n_global
     value = total_steps / dt
     # roofline of the dominant kernel (pt_round_kernel): ALGORITHMIC bytes per launch / avg launch duration
     bytes_per_step = w.bytes_per_step()
     launch_ms = ev_ms.value / max(launches.value, 1)
-    steps_per_launch = (a.steps * R * n_swap * n_local) / max(launches.value, 1)
+    steps_per_launch = (a.steps * LPS * R * n_swap * n_local) / max(launches.value, 1)
     achieved_gbs = bytes_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9
     # fp64 operations per data point as the kernels issue them, an FMA counted as two:
     # a sine with its argument is 28 (3 + reduction 7 + polynomial 18); simplesin adds 5 around it,
@@ -246,18 +264,60 @@ def main():
     modes = max(1, (w.n_par - 2) // 2)
     flops_per_point = {"simplesin": 33.0, "sine3": 3 * 30.0 + 4, "pulse": 19.0 * modes + 50, "pulse_vrot": 99.0}
     flops_per_step = flops_per_point.get(w.name, 40.0) * w.n_data
-    # HBM bytes per launch come from the PMC counters, which cannot be read inside this process:
-    # `traffic` stays null in this line; the figure profiled with `rocprofv3 --pmc` on this same
-    # command (profiles/README.md) is quoted as `traffic_profiled` when the workload is the one it
-    # was measured on
-    traffic_profiled = None
+    # What the PMC counters say cannot be read inside this process: `traffic` stays null in this line;
+    # the HBM bytes and the VALU instruction count profiled with `rocprofv3 --pmc` on this same command
+    # (profiles/README.md, profiles/pmc_traffic.json) are quoted when the workload is the one they
+    # were measured on.
+    traffic_profiled = valu_insts = profile_src = None
     key = "%s/%d/%d/%d/%d/%s" % (w.name, n_local, w.n_data, n_swap, R, "nosamples" if a.no_samples else "samples")
     try:
         for pmc in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
-            if pmc.get("workload_key") == key and world == 1 and pmc.get("waves_per_chain", waves) == waves:
-                traffic_profiled = pmc["hbm_bytes_per_launch"]
+            if pmc.get("workload_key") == key and pmc.get("waves_per_chain", waves) == waves:
+                traffic_profiled = pmc.get("hbm_bytes_per_launch")
+                valu_insts = pmc.get("valu_wave_insts_per_launch", valu_insts)
+                profile_src = pmc.get("tag", profile_src)
     except (OSError, ValueError, KeyError, TypeError):
         pass
+    # The roofline that binds.  The data vector is resident in LDS or L2 by design (HBM traffic is
+    # well under 1 % of the algorithmic bytes), so no kernel of this engine is bound by HBM: what a
+    # step costs is instructions -- one wave64 VALU instruction occupies its SIMD for four cycles,
+    # integer or fp64 -- and, on ladders smaller than the chip, the CUs that have no chain.  `frac` is
+    # against the whole chip; `frac_on_occupied_simds` says how busy the SIMDs that hold a chain are.
+    props = torch.cuda.get_device_properties(local_rank)
+    clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+    cus = props.multi_processor_count
+    one_barrier = waves in (4, 8) and not (a.flags & 4)
+    waves_per_wg = waves + 4 if one_barrier else waves
+    cus_occupied = min(cus, n_local)
+    simds_occupied = min(4 * cus, n_local * min(4, waves_per_wg))
+    launch_s = launch_ms * 1e-3
+    fp64_frac = flops_per_step * steps_per_launch / launch_s / 1e12 / FP64_VALU_PEAK_TF
+    roof = {"traffic": None, "traffic_profiled": traffic_profiled,
+            "kernel": "pt_round_ob_kernel" if one_barrier else "pt_round_kernel", "launch_us": launch_ms * 1e3,
+            "cus_occupied": cus_occupied, "cus": cus, "simds_occupied": simds_occupied, "clock_mhz_peak": clock_hz / 1e6,
+            # SURVEY 8(d)'s nominal figure: every step "streams" the data vector once (it does, from LDS / L2)
+            "hbm_nominal_achieved": achieved_gbs, "hbm_nominal_peak": HBM_PEAK_GBS, "hbm_nominal_unit": "GB/s",
+            "hbm_nominal_frac": achieved_gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": bytes_per_step * steps_per_launch,
+            "fp64_valu_frac": fp64_frac}
+    if valu_insts:
+        issue_peak = 4 * cus * clock_hz / 4.0
+        issue = valu_insts / launch_s
+        roof.update({"bound": "valu_issue", "achieved": issue / 1e9, "peak": issue_peak / 1e9,
+                     "unit": "G wave-instructions/s", "frac": issue / issue_peak,
+                     "frac_on_occupied_simds": issue / (simds_occupied * clock_hz / 4.0),
+                     "valu_wave_insts_per_step_per_occupied_simd": valu_insts / steps_per_launch * n_local / simds_occupied,
+                     "issue_source": "SQ_INSTS_VALU of this kernel under rocprofv3 --pmc, same command (profiles/%s)" % profile_src})
+    else:
+        roof.update({"bound": "fp64_valu", "achieved": fp64_frac * FP64_VALU_PEAK_TF, "peak": FP64_VALU_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": fp64_frac,
+                     "issue_source": "no profiled instruction count for this workload: fp64 flops of the likelihood as issued (an FMA = 2)"})
+    parallel = {"ranks": world, "backend": dist.get_backend() if use_dist else None,
+                "n_swap_rule": "explicit" if a.n_swap else a.n_swap_rule}
+    if per_rank is not None:
+        rates = a.steps * LPS * R * n_swap * n_local / per_rank[:, 0]
+        parallel.update({"rank_steps_per_s_min": float(rates.min()), "rank_steps_per_s_max": float(rates.max()),
+                         "edge_exchanges_all_ranks": int(per_rank[:, 1].sum())})
     out = {
         "metric": "MCMC steps/sec (all chains) on %s, 1/2/4/8 MI355X + HBM-roofline %%" % w.name,
         "baseline_config": a.config,
@@ -265,23 +325,15 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d beta-chains/GPU x %d GPU, %d data points, n_par=%d, n_swap=%d, "
-                               "%d rounds per bench step, sample rows %s" %
-                               (w.name, n_local, world, w.n_data, w.n_par, n_swap, R,
+                               "%d launches x %d rounds per bench step, sample rows %s" %
+                               (w.name, n_local, world, w.n_data, w.n_par, n_swap, LPS, R,
                                 "off" if a.no_samples else "on"),
                    "chains_per_gpu": n_local, "n_data": w.n_data, "n_swap": n_swap, "rounds_per_step": R,
+                   "launches_per_step": LPS,
                    "waves_per_chain": waves, "data_in_lds": lds, "parallelism": "ladder-sharded x%d" % world,
-                   "edge_exchanges_rank0": ladder.exchanges,
+                   "edge_exchanges_rank0": ladder.exchanges, "distributed": parallel,
                    "device_calibrated_chains_rank0": calibrated, "acceptance_rate_rank0": acceptance},
-        # `bound: hbm` is the nominal roofline of SURVEY 8(d) (algorithmic bytes: every step streams the
-        # data vector once); the data vector is LDS/L2-resident by design, so what actually limits the
-        # kernel is fp64 issue + the serial accept chain: see `limited_by` and `fp64_valu_frac`
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": traffic_profiled,
-                     "limited_by": "fp64 issue / dependent-operation latency (data vector resident in LDS or L2)",
-                     "kernel": "pt_round_ob_kernel" if (waves in (4, 8) and not (a.flags & 4)) else "pt_round_kernel", "launch_us": launch_ms * 1e3,
-                     "algorithmic_bytes_per_launch": bytes_per_step * steps_per_launch,
-                     "fp64_valu_frac": flops_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e12
-                                       / FP64_VALU_PEAK_TF},
+        "roofline": roof,
     }
     if calibration is not None:
         # the calibration's likelihood evaluations per second against the round kernel's on the same ladder
@@ -292,7 +344,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, acc0, n_swap, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if a.maps_dump:
+        open(a.maps_dump, "w").write(open("/proc/self/maps").read())
     s.close()
     if use_dist:
         dist.destroy_process_group()

@@ -26,8 +26,15 @@
 #ifndef APEMOST_HIP_H
 #define APEMOST_HIP_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stddef.h>
 #include <stdint.h>
+#else /* compiled by hiprtc (a user-supplied device model): no C library headers, its own fixed-width types */
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,7 +57,11 @@ enum {
     APEMOST_MODEL_SIMPLESIN = 0,  /* apps/simplesin.c:12-38   n_par = 4            */
     APEMOST_MODEL_PULSE = 1,      /* apps/pulse.c:12-54       n_par = 2 + 2*modes  */
     APEMOST_MODEL_PULSE_VROT = 2, /* apps/pulse_vrot.c:12-65  n_par = 7            */
-    APEMOST_MODEL_SINE3 = 3       /* 10-parameter 3-sinusoid model  */
+    APEMOST_MODEL_SINE3 = 3,      /* 10-parameter 3-sinusoid model  */
+    /* any other calc_model(): device source supplied by the user (apemost_device_model.h), named in
+     * apemost_hip_config.device_model_source and compiled with hiprtc when the sampler is created;
+     * any n_par; runs in the one-wave kernels */
+    APEMOST_MODEL_USER = 4
 };
 
 /* BETA_ALIGNMENT choices, src/parallel_tempering_beta.c:53-83 */
@@ -142,6 +153,8 @@ typedef struct {
                                * redrawn (-DCIRCULAR_PARAMS, src/markov_chain.c:241-265) */
     double adapt_target;      /* TARGET_ACCEPTANCE_RATE (src/define_defaults.h:77-79) for
                                * APEMOST_HIP_FLAG_ADAPT; 0 = the reference's default 0.5 */
+    const char *device_model_source; /* APEMOST_MODEL_USER: path of the device source of the likelihood
+                                      * (include/apemost_device_model.h); NULL otherwise */
 } apemost_hip_config;
 
 /* Host-side structure-of-arrays view of n_chains chains; any pointer may be NULL

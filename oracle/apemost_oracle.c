@@ -303,6 +303,61 @@ static double ll_pulse_vrot(const double *p, const double *data, int n, int nc, 
     return prior + -beta * prob;
 }
 
+/* The reference's other example likelihoods: checkers for the engine's
+ * user-supplied device models (apemost_amd/host/examples/device_models/). */
+/* apps/simplesin2.c:12-34: amplitude and frequency, phase fixed at 0.3312 */
+static double ll_sine2(const double *p, const double *data, int n, int nc, double beta, double sigma) {
+    double square_sum = 0;
+    int i;
+    for (i = 0; i < n; i++) {
+        double x = data[(size_t)i * nc];
+        double y = p[0] * sin(2.0 * M_PI * (p[1] * x + 0.3312)) - data[(size_t)i * nc + 1];
+        square_sum += y * y;
+    }
+    return beta * square_sum / (-2 * sigma * sigma);
+}
+
+/* apps/normal.c:8-34: one parameter, ten peaks, the tallest one counts */
+static double ll_normal(const double *p, double beta) {
+    double x = p[0], a, b = 0, sigma, pos, height;
+    unsigned int i;
+    for (i = 0; i < 10; i++) {
+        pos = exp(i);
+        height = 10 * pow(1.0, i);
+        sigma = i;
+        if (i % 2 == 0)
+            a = -sigma * pow((x - pos) / sigma, 2) / 2 + height;
+        else if (x > pos)
+            a = -height * (x - pos) / sigma + height;
+        else
+            a = -height * (pos - x) / sigma + height;
+        if (a > b)
+            b = a;
+    }
+    return beta * b;
+}
+
+/* apps/bernoulli_example.c:10-49 (its own SIGMA 2): column 0 the outcome, columns 1.. the regressors */
+static double ll_bernoulli(int n_par, const double *p, const double *data, int n, int nc, double beta,
+                           double *prior_out) {
+    double prior = 0, prob = 0;
+    int i, j;
+    for (j = 1; j < nc; j++)
+        prior += -pow(p[j] / 2, 2) / 2;
+    for (i = 0; i < n; i++) {
+        double eta_i = p[0], p_i;
+        for (j = 1; j < n_par; j++)
+            eta_i += data[(size_t)i * nc + j] * p[j];
+        if (eta_i > 0)
+            p_i = 1 / (1 + exp(-eta_i));
+        else
+            p_i = exp(eta_i) / (1 + exp(eta_i));
+        prob += data[(size_t)i * nc] == 0 ? log(1 - p_i) : log(p_i);
+    }
+    *prior_out = prior;
+    return prior + beta * prob;
+}
+
 double orc_loglike(int model, int n_par, const double *params, const double *data,
                    int n_data, int n_cols, double beta, double sigma, double hmin,
                    double *prior_out) {
@@ -320,6 +375,15 @@ double orc_loglike(int model, int n_par, const double *params, const double *dat
     case ORC_MODEL_PULSE_VROT:
         prob = ll_pulse_vrot(params, data, n_data, n_cols, beta, hmin, &prior);
         break;
+    case ORC_MODEL_SINE2:
+        prob = ll_sine2(params, data, n_data, n_cols, beta, sigma);
+        break;
+    case ORC_MODEL_NORMAL:
+        prob = ll_normal(params, beta);
+        break;
+    case ORC_MODEL_BERNOULLI:
+        prob = ll_bernoulli(n_par, params, data, n_data, n_cols, beta, &prior);
+        break;
     default:
         prob = NAN;
     }
@@ -335,7 +399,7 @@ void orc_calc_model(orc_state *s, int c) {
     double prob = orc_loglike(s->model, s->n_par, s->params + (size_t)c * s->n_par, s->data,
                               s->n_data, s->n_cols, s->beta[c], s->sigma, s->hmin, &prior);
     s->prob[c] = prob;
-    if (s->model == ORC_MODEL_PULSE || s->model == ORC_MODEL_PULSE_VROT)
+    if (s->model == ORC_MODEL_PULSE || s->model == ORC_MODEL_PULSE_VROT || s->model == ORC_MODEL_BERNOULLI)
         s->prior[c] = prior;
 }
 

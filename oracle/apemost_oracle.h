@@ -30,7 +30,11 @@ enum {
     ORC_MODEL_SIMPLESIN = 0,  /* apps/simplesin.c:12-38, n_par = 4          */
     ORC_MODEL_PULSE = 1,      /* apps/pulse.c:12-54, n_par = 2 + 2*modes    */
     ORC_MODEL_PULSE_VROT = 2, /* apps/pulse_vrot.c:12-65, n_par = 7         */
-    ORC_MODEL_SINE3 = 3       /* own 10-parameter model, SURVEY N3           */
+    ORC_MODEL_SINE3 = 3,      /* own 10-parameter model, SURVEY N3           */
+    /* the reference's other examples, for the engine's user-supplied device models */
+    ORC_MODEL_SINE2 = 4,      /* apps/simplesin2.c:12-34, n_par = 2          */
+    ORC_MODEL_NORMAL = 5,     /* apps/normal.c:8-34, n_par = 1               */
+    ORC_MODEL_BERNOULLI = 6   /* apps/bernoulli_example.c:10-49, n_par = n_cols */
 };
 
 /* ---- beta ladders (src/parallel_tempering_beta.c:53-83) ---------------- */

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libapemost_oracle.so")
 
 MODEL_SIMPLESIN, MODEL_PULSE, MODEL_PULSE_VROT, MODEL_SINE3 = 0, 1, 2, 3
+MODEL_SINE2, MODEL_NORMAL, MODEL_BERNOULLI = 4, 5, 6   # apps/simplesin2.c, normal.c, bernoulli_example.c
 RNG_GLOBAL_MT, RNG_STREAMS = 0, 1
 PROPOSAL_GAUSSIAN, PROPOSAL_LOGISTIC, PROPOSAL_UNIFORM = 0, 1, 2
 (LADDER_CHEBYSHEV_BETA, LADDER_EQUIDISTANT_BETA, LADDER_EQUIDISTANT_TEMPERATURE,

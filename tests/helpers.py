@@ -58,8 +58,9 @@ class OracleShardEngine:
     """ShardedLadder engine backed by the CPU oracle (test infrastructure): lets the sharding and
     edge-exchange host logic run under gloo without a GPU.  Same interface as HipShardEngine."""
 
-    def __init__(self, lad, seed, n_global, torch):
+    def __init__(self, lad, seed, n_global, torch, max_rounds=5):
         import contextlib
+        self.max_rounds = max_rounds
         self.lad, self.n_global, self.torch, self.seed = lad, n_global, torch, seed
         self.rng = orc.Rng(orc.RNG_STREAMS, seed, lad)
         self.halo = {0: None, 1: None}
@@ -97,7 +98,7 @@ class OracleShardEngine:
         self.halo[side] = buf.numpy().copy()
 
     def max_rounds_per_launch(self):
-        return 5
+        return self.max_rounds
 
     def launch_rounds(self, n_rounds, n_steps, apply_swap, samples):
         for j in range(n_rounds):

@@ -64,6 +64,12 @@ def test_reference_apps_link_unchanged_and_eval_matches_manual(tmp_path):
         for main in ("generic_main", "eval_main", "benchmark_main"):
             _make(str(tmp_path / ("%s_%s.exe" % (main, app))), app="%s/apps/%s.c" % (REF, app),
                   main="%s/apps/%s.c" % (REF, main), ccflags="-DN_BETA=8")
+    # the reference's other example likelihoods: they sample through a device model
+    # given as source (APEMOST_DEVICE_MODEL_SRC, examples/device_models/), and link unchanged
+    for app in ("simplesin2", "normal", "bernoulli_example"):
+        _make(str(tmp_path / ("generic_main_%s.exe" % app)), app="%s/apps/%s.c" % (REF, app),
+              main="%s/apps/generic_main.c" % REF, ccflags="-DN_BETA=8")
+        assert os.path.exists(os.path.join(HOST, "examples", "device_models", app + ".hip"))
     # doc/manual.rst:190-213: the eval example, host plugin path only (no GPU involved)
     work = tmp_path / "w"
     work.mkdir()

@@ -8,7 +8,7 @@
 #   write : --pmc WRITE_SIZE                -> HBM write side
 #   sq    : --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY
 #                 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY   (8 SQ slots)
-set -e -o pipefail
+set -o pipefail
 cfg=$1; tag=$2; shift 2
 out=gpurun_out/$tag
 mkdir -p $out
@@ -21,4 +21,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- p
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY \
     --kernel-trace --output-format csv -d $out/sq -- python3 bench.py $common > $out/sq.log 2>&1
 python3 tools/summarize_profile.py $tag $cfg
+# the calibration launches of the same runs (markov_chain_calibrate before the timed steps)
+python3 tools/summarize_profile.py $tag $cfg pt_calibrate calib
 echo "profiled config $cfg -> $out"

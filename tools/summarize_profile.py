@@ -22,12 +22,12 @@ def counter_rows(d):
     return rows
 
 
-def dominant(rows):
-    """the kernel with the largest total duration among pt_* kernels"""
+def dominant(rows, family="pt_round"):
+    """the kernel with the largest total duration among the kernels of one family"""
     tot = {}
     for r in rows:
         k = r["Kernel_Name"]
-        if "pt_round" in k:
+        if family in k:
             tot[k] = tot.get(k, 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return max(tot, key=tot.get) if tot else None
 
@@ -53,7 +53,12 @@ def per_launch(rows, kernel, min_us=0.0):
 
 
 def main():
+    """summarize_profile.py <tag> <config> [family [suffix]]: family = substring that selects the kernels
+    (default pt_round; pt_calibrate for the calibration launches of the same runs), suffix = inserted
+    into the output file name"""
     tag, cfg = sys.argv[1], sys.argv[2]
+    family = sys.argv[3] if len(sys.argv) > 3 else "pt_round"
+    suffix = ("_" + sys.argv[4]) if len(sys.argv) > 4 else ""
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
@@ -70,7 +75,7 @@ def main():
         rows = counter_rows(os.path.join(src, name))
         if not rows:
             continue
-        kernel = kernel or dominant(rows)
+        kernel = kernel or dominant(rows, family)
         vals, med_us, n = per_launch(rows, kernel)
         out.setdefault("kernel", kernel)
         out[name] = {"launches": n, "median_launch_us": med_us,
@@ -98,8 +103,22 @@ def main():
             "lds_insts_per_wave": sq.get("SQ_INSTS_LDS", 0) / sq["SQ_WAVES"] if sq.get("SQ_WAVES") else None,
             "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, summed over all waves",
         }
-    with open(os.path.join(dst, tag + "_counters.json"), "w") as fh:
+    if sq.get("SQ_INSTS_VALU"):
+        out["valu_wave_insts_per_launch"] = sq["SQ_INSTS_VALU"]
+    with open(os.path.join(dst, tag + suffix + "_counters.json"), "w") as fh:
         json.dump(out, fh, indent=1)
+    # what bench.py quotes as roofline.traffic_profiled / the instruction count of its issue roofline
+    bl = out.get("bench_line", {}).get("config")
+    if family == "pt_round" and bl and "hbm_bytes_per_launch" in out and len(sys.argv) <= 3:
+        reg = os.path.join(dst, "pmc_traffic.json")
+        key = "%s/%d/%d/%d/%d/%s" % (out["bench_line"]["metric"].split(" on ")[1].split(",")[0], bl["chains_per_gpu"], bl["n_data"],
+                                     bl["n_swap"], bl["rounds_per_step"], "samples")
+        entries = [e for e in json.load(open(reg)) if e.get("workload_key") != key or e.get("waves_per_chain", bl["waves_per_chain"]) != bl["waves_per_chain"]]
+        entries.append({"tag": tag + "_counters.json", "source": out["command"] + ", MI355X", "kernel": out.get("kernel"),
+                        "workload_key": key, "waves_per_chain": bl["waves_per_chain"],
+                        "hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "correction": out.get("hbm_correction"),
+                        "valu_wave_insts_per_launch": out.get("valu_wave_insts_per_launch")})
+        json.dump(entries, open(reg, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("kernel", "registers", "hbm_bytes_per_launch", "sq_ratios") if k in out}, indent=1))
 
 
