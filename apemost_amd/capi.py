@@ -62,7 +62,7 @@ EXPORTS = [
     "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_launch_rounds", "apemost_hip_max_rounds_per_launch",
     "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
     "apemost_hip_samples_read", "apemost_hip_samples_free", "apemost_hip_samples_read_async",
-    "apemost_hip_samples_wait", "apemost_hip_host_alloc", "apemost_hip_host_free", "apemost_hip_swap_pair",
+    "apemost_hip_samples_wait", "apemost_hip_samples_pack_read_async", "apemost_hip_host_alloc", "apemost_hip_host_free", "apemost_hip_swap_pair",
     "apemost_hip_sampler_swap_pair", "apemost_hip_rounds_within_shard",
     "apemost_hip_edge_doubles", "apemost_hip_edge_export", "apemost_hip_edge_import",
     "apemost_hip_edge_exchange", "apemost_hip_run_shards",
@@ -122,6 +122,8 @@ def lib():
     L.apemost_hip_samples_read.argtypes = [vp, vp, C.c_uint64, _dp]
     L.apemost_hip_samples_free.argtypes = [vp, vp]
     L.apemost_hip_samples_read_async.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    L.apemost_hip_samples_pack_read_async.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
+                                                      vp, vp, vp, _up]
     L.apemost_hip_samples_wait.argtypes = [vp]
     L.apemost_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.apemost_hip_host_free.argtypes = [vp]

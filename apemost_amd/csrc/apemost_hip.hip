@@ -79,6 +79,35 @@ __global__ void pt_adapt_kernel(DevArrays d, double target) {
     }
 }
 
+// Sample rows [n_steps][n_chains][n_par+2] -> what a sink writes, for the kept steps skip, skip + thin, ...
+// layout 0: the record of the C host's binary sink (apemost_amd/host/src/parallel_tempering.c): the
+//   parameter vectors of chains 0..n_param_chains-1, then (prob, prob - prior) of every chain;
+// layout 1: the rows themselves, thinned.
+// One thread per output double: coalesced writes, gathered reads; a few KB per step against HBM.
+__global__ void samples_pack_kernel(const double *rows, int n_chains, int n_par, unsigned long long n_kept,
+                                    unsigned long long skip, unsigned long long thin, int n_param_chains, int layout,
+                                    double *out) {
+    const size_t row = (size_t)n_chains * (n_par + 2);
+    const size_t record = layout == 0 ? (size_t)n_param_chains * n_par + 2 * (size_t)n_chains : row;
+    const size_t total = (size_t)n_kept * record;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = i / record, r = i - k * record;
+        const double *src = rows + (skip + k * thin) * row;
+        size_t from = r;
+        if (layout == 0) {
+            const size_t head = (size_t)n_param_chains * n_par;
+            if (r < head) {
+                const size_t chain = r / n_par;
+                from = chain * (n_par + 2) + (r - chain * n_par);
+            } else {
+                const size_t q = r - head;
+                from = (q >> 1) * (n_par + 2) + n_par + (q & 1);
+            }
+        }
+        out[i] = src[from];
+    }
+}
+
 __global__ void edge_export_kernel(DevArrays d, int n_par, int cur, int row, double *buf) {
     const int t = threadIdx.x;
     if (t == 0) {
@@ -1202,6 +1231,46 @@ extern "C" int apemost_hip_samples_read_async(apemost_hip_sampler *s, const doub
     HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_copy, 0));
     const size_t bytes = (size_t)n_steps * n * (s->cfg.n_par + 2) * sizeof(double);
     HIP_TRY(hipMemcpyAsync(host_samples, d_samples, bytes, hipMemcpyDeviceToHost, s->copy_stream));
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_samples_pack_read_async(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
+                                                   uint64_t skip, uint64_t thin, int32_t n_param_chains, int32_t layout,
+                                                   double *d_packed, double *host_packed, uint64_t *counters,
+                                                   uint64_t *n_kept) {
+    CHECK_S(s);
+    if (!d_samples || !d_packed || !host_packed || thin < 1 || (layout != 0 && layout != 1) || n_param_chains < 0 ||
+        n_param_chains > s->cfg.n_chains)
+        return fail(APEMOST_HIP_ERR_INVALID, "samples_pack_read_async: bad arguments");
+    if (!s->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_copy, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **)&s->h_word, sizeof(u64), hipHostMallocDefault));
+        *s->h_word = 0;
+    }
+    const size_t n = s->cfg.n_chains, np = s->cfg.n_par;
+    const uint64_t kept = skip < n_steps ? (n_steps - skip + thin - 1) / thin : 0;
+    const size_t record = layout == 0 ? (size_t)n_param_chains * np + 2 * n : n * (np + 2);
+    if (n_kept)
+        *n_kept = kept;
+    if (kept > 0) {
+        const size_t total = (size_t)kept * record;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 65535)
+            blocks = 65535;
+        hipLaunchKernelGGL(samples_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s->stream, d_samples, (int)n, (int)np,
+                           (unsigned long long)kept, (unsigned long long)skip, (unsigned long long)thin, (int)n_param_chains,
+                           (int)layout, d_packed);
+        HIP_TRY(hipGetLastError());
+    }
+    if (counters)
+        HIP_TRY(hipMemcpyAsync(counters, s->d.accept(), 2 * n * sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_word, s->d.timeout_word(), sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->ev_copy, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_copy, 0));
+    if (kept > 0)
+        HIP_TRY(hipMemcpyAsync(host_packed, d_packed, (size_t)kept * record * sizeof(double), hipMemcpyDeviceToHost,
+                               s->copy_stream));
     return APEMOST_HIP_OK;
 }
 

@@ -66,6 +66,45 @@ void markov_chain_step_for(mcmc *m, const unsigned int index) {
     gsl_vector_free(best);
 }
 
+/* n Metropolis updates of one kind in ONE launch (which < 0: markov_chain_step, else
+ * markov_chain_step_for(m, which)), each followed by mcmc_check_best as the round kernel does it;
+ * accepted[k] = step k moved the chain (its sample row differs from the one before: a proposal is a
+ * continuous draw, so an accepted step never lands on the point it started from).  One upload, one
+ * launch and one download for the whole batch instead of one of each per step. */
+static void steps_on_device(mcmc *m, int which, unsigned int n, unsigned char *accepted) {
+    apemost_ladder *l;
+    apemost_hip_sampler *s;
+    const unsigned int n_par = get_n_par(m);
+    const unsigned long n_iter = m->n_iter;
+    const size_t row = n_par + 2;
+    double *d_rows = NULL, *rows = (double *)malloc((size_t)(n + 1) * row * sizeof(double));
+    unsigned int k, p;
+    assert(rows != NULL);
+    mcmc_check(m);
+    for (p = 0; p < n_par; p++)
+        rows[p] = gsl_vector_get(m->params, p); /* the point the first step starts from */
+    l = apemost_single(m);
+    s = apemost_ladder_sampler(l);
+    apemost_ladder_upload(l);
+    apemost_hip_or_die(apemost_hip_samples_alloc(s, n, &d_rows), "samples_alloc");
+    if (which < 0)
+        apemost_hip_or_die(apemost_hip_launch_round(s, n, 0, d_rows), "markov_chain_step");
+    else
+        apemost_hip_or_die(apemost_hip_launch_round_for(s, n, which, d_rows), "markov_chain_step_for");
+    apemost_hip_or_die(apemost_hip_samples_read(s, d_rows, n, rows + row), "samples_read");
+    apemost_hip_or_die(apemost_hip_samples_free(s, d_rows), "samples_free");
+    apemost_ladder_download(l);
+    m->n_iter = n_iter; /* (the steps of this API do not count as iterations) */
+    for (k = 0; k < n; k++) {
+        const double *was = rows + (size_t)k * row, *is = was + row;
+        accepted[k] = 0;
+        for (p = 0; p < n_par; p++)
+            if (is[p] != was[p])
+                accepted[k] = 1;
+    }
+    free(rows);
+}
+
 void burn_in(mcmc *m, const unsigned int burn_in_iterations) {
     apemost_ladder *l = apemost_single(m);
     apemost_hip_calib_config c;
@@ -131,7 +170,8 @@ void rmw_adapt_stepwidth(mcmc *m, const double prob_old) {
 /* assess_acceptance_rate (reference src/markov_chain.c:117-224; used by the alternate calibrators
  * and by applications that tune widths themselves): measure the acceptance rate of parameter
  * `param` (or of the all-parameter step when param >= n_par) to an accuracy that tightens as the
- * rate approaches the desired one.  Every step is a device step (markov_chain_step[_for]).
+ * rate approaches the desired one.  Every step is a device step (markov_chain_step[_for]), a batch
+ * of them per launch.
  *
  * The estimate follows the reference to the letter, including two things a reader might not
  * expect: the rate is (accepts before the LAST step of the batch) / n, and the drift of the
@@ -150,14 +190,11 @@ unsigned int assess_acceptance_rate(mcmc *m, unsigned int param, double desired_
         double rate, wanted;
         accepted = (unsigned char *)realloc(accepted, n);
         assert(accepted != NULL);
-        for (; done < n; done++) {
-            before = single ? get_params_accepts_for(m, param) : get_params_accepts_global(m);
-            if (single)
-                markov_chain_step_for(m, param);
-            else
-                markov_chain_step(m);
-            mcmc_check_best(m);
-            accepted[done] = before != (single ? get_params_accepts_for(m, param) : get_params_accepts_global(m));
+        if (done < n) {
+            /* the steps done+1 .. n in one launch; `before` = the count ahead of the last one */
+            steps_on_device(m, single ? (int)param : -1, n - done, accepted + done);
+            done = n;
+            before = (single ? get_params_accepts_for(m, param) : get_params_accepts_global(m)) - accepted[n - 1];
         }
         rate = before / (double)n;
         for (j = 0; j < n; j++) {

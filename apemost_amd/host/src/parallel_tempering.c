@@ -371,6 +371,41 @@ static void sink_write(sample_sink *k, mcmc **chains, double *const *h, const un
     k->batches++;
 }
 
+/* the same batch when the device has already packed it (apemost_hip_samples_pack_read_async; one
+ * shard): binary sinks write the pinned buffer as it is, the thinned text sink finds the kept rows
+ * [kept][n_beta][n_par+2] */
+static void sink_write_packed(sample_sink *k, mcmc **chains, const double *packed, unsigned long kept) {
+    const unsigned int n_par = k->n_par;
+    unsigned long step;
+    unsigned int i, p;
+    char name[100];
+    if (k->binary) {
+        const size_t record = (size_t)k->n_param_chains * n_par + 2 * (size_t)k->n_beta;
+        fwrite(packed, sizeof(double), kept * record, k->bin);
+        k->batches++;
+        return;
+    }
+    for (i = 0; i < k->n_beta; i++) {
+        FILE *pf = k->prob_files ? k->prob_files[i] : NULL;
+        FILE **vf = chains[i]->files;
+        if (pf == NULL) {
+            sprintf(name, "prob-chain%d.dump", i);
+            pf = open_or_die(name, k->batches == 0 ? k->mode : "a");
+        }
+        for (step = 0; step < kept; step++) {
+            const double *r = packed + (step * k->n_beta + i) * (size_t)(n_par + 2);
+            if (vf != NULL)
+                for (p = 0; p < n_par; p++)
+                    if (vf[p] != NULL)
+                        fprintf(vf[p], DUMP_FORMAT "\n", r[p]);
+            fprintf(pf, "%6e\t%6e\n", r[n_par], r[n_par + 1]);
+        }
+        if (k->prob_files == NULL)
+            fclose(pf);
+    }
+    k->batches++;
+}
+
 static void sink_flush(sample_sink *k) {
     unsigned int i;
     if (k->bin)
@@ -413,8 +448,9 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
     /* double-buffered per shard: device rows, pinned host rows, pinned accept/reject snapshot */
     double *d_samples[2][APEMOST_MAX_SHARDS], *h_samples[2][APEMOST_MAX_SHARDS];
     uint64_t *h_counts[2][APEMOST_MAX_SHARDS];
+    double *d_packed[2] = {NULL, NULL};
     unsigned int lo[APEMOST_MAX_SHARDS + 1], n_shards, i, j;
-    int k = 0;
+    int k = 0, device_pack;
 
     if (max_rounds < 1)
         max_rounds = 1;
@@ -448,6 +484,13 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
             apemost_hip_or_die(apemost_hip_host_alloc(2 * n_local * sizeof(uint64_t), &p), "host_alloc");
             h_counts[i][j] = (uint64_t *)p;
         }
+    /* One shard and a sink that does not want every row as it is (binary records, thinning): the
+     * device packs each batch into what will be written, so that only that crosses PCIe and the host
+     * writes the pinned buffer without touching it. */
+    device_pack = n_shards == 1 && (sink.binary || sink.thin > 1);
+    for (i = 0; i < 2 && device_pack; i++)
+        apemost_hip_or_die(apemost_hip_samples_alloc(apemost_ladder_shard(l, 0), max_rounds * n_swap, &d_packed[i]),
+                           "samples_alloc");
     get_duration();
     run = 1;
     dumpflag = 0;
@@ -471,7 +514,14 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
         apemost_ladder_run(l, rounds_now, n_swap, d_samples[k]);
     while (rounds_now > 0) {
         const unsigned long n_steps = rounds_now * n_swap, iter_after = iter + n_steps;
-        for (j = 0; j < n_shards; j++)
+        uint64_t kept = 0;
+        if (device_pack)
+            apemost_hip_or_die(apemost_hip_samples_pack_read_async(apemost_ladder_shard(l, 0), d_samples[k][0], n_steps,
+                                                                   (sink.thin - (iter % sink.thin) - 1) % sink.thin, sink.thin,
+                                                                   (int32_t)sink.n_param_chains, sink.binary ? 0 : 1, d_packed[k],
+                                                                   h_samples[k][0], h_counts[k][0], &kept),
+                               "samples_pack_read_async");
+        for (j = 0; j < n_shards && !device_pack; j++)
             apemost_hip_or_die(apemost_hip_samples_read_async(apemost_ladder_shard(l, j), d_samples[k][j], n_steps,
                                                               h_samples[k][j], h_counts[k][j]),
                                "samples_read_async");
@@ -480,12 +530,19 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
             apemost_ladder_run(l, rounds_next, n_swap, d_samples[k ^ 1]);
         for (j = 0; j < n_shards; j++)
             apemost_hip_or_die(apemost_hip_samples_wait(apemost_ladder_shard(l, j)), "samples_wait");
-        sink_write(&sink, chains, h_samples[k], lo, n_shards, iter, n_steps);
+        if (device_pack)
+            sink_write_packed(&sink, chains, h_samples[k][0], (unsigned long)kept);
+        else
+            sink_write(&sink, chains, h_samples[k], lo, n_shards, iter, n_steps);
         iter = iter_after;
         apemost_swap_round += rounds_now;
         if (iter % PRINT_PROB_INTERVAL == 0) {
             /* chain 0's latest row and counters live in shard 0 */
-            const double *last = h_samples[k][0] + (n_steps - 1) * (size_t)(lo[1] - lo[0]) * (n_par + 2);
+            /* (a packed batch holds the kept iterations only: then the latest kept one, whose record
+             * begins with chain 0's parameters wherever it has any) */
+            const double *last = !device_pack ? h_samples[k][0] + (n_steps - 1) * (size_t)(lo[1] - lo[0]) * (n_par + 2)
+                                 : h_samples[k][0] + (kept > 0 ? kept - 1 : 0) *
+                                       (sink.binary ? (size_t)sink.n_param_chains * n_par + 2 * (size_t)n_beta : row);
             const uint64_t accept0 = h_counts[k][0][0], reject0 = h_counts[k][0][lo[1] - lo[0]];
             if (dumpflag) {
                 /* a report on request: the ladder as the device holds it now (a batch ahead of
@@ -520,6 +577,9 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
             apemost_hip_host_free(h_samples[i][j]);
             apemost_hip_host_free(h_counts[i][j]);
         }
+    for (i = 0; i < 2; i++)
+        if (d_packed[i] != NULL)
+            apemost_hip_samples_free(apemost_ladder_shard(l, 0), d_packed[i]);
     apemost_ladder_close(l);
     fclose(acceptance_file);
     sink_close(&sink);

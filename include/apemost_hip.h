@@ -285,6 +285,17 @@ int apemost_hip_samples_free(apemost_hip_sampler *s, double *d_samples);
  * such read has landed (and reports a void launch like apemost_hip_samples_read). */
 int apemost_hip_samples_read_async(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
                                    double *host_samples, uint64_t *counters);
+/* The same with the rows packed ON THE DEVICE into what the sink will write, so that only that crosses
+ * PCIe and the host writes the pinned buffer as it is: of the n_steps rows the steps skip, skip + thin,
+ * ... are kept (*n_kept of them);
+ *   layout 0: per kept step the parameter vectors of chains 0 .. n_param_chains-1, then
+ *             (prob, prob - prior) of every chain  -- the record of the C host's binary sink;
+ *   layout 1: the kept rows themselves, [n_kept][n_chains][n_par+2].
+ * d_packed: DEVICE scratch for the packed batch (apemost_hip_samples_alloc sizes fit), host_packed:
+ * pinned; counters and the wait as for apemost_hip_samples_read_async. */
+int apemost_hip_samples_pack_read_async(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
+                                        uint64_t skip, uint64_t thin, int32_t n_param_chains, int32_t layout,
+                                        double *d_packed, double *host_packed, uint64_t *counters, uint64_t *n_kept);
 int apemost_hip_samples_wait(apemost_hip_sampler *s);
 /* page-locked host memory for those reads */
 int apemost_hip_host_alloc(size_t bytes, void **p);
