@@ -149,7 +149,7 @@ def lib():
     L.apemost_hip_calibrate_cancel.argtypes = [vp]
     L.apemost_hip_calibrate_wait_any.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(C.c_int32)]
     L.apemost_hip_calibrate_progress.argtypes = [vp, _dp, C.c_int32, C.POINTER(C.c_int32)]
-    L.apemost_hip_calibrate_stats.argtypes = [vp, _up, _up, _up]
+    L.apemost_hip_calibrate_stats.argtypes = [vp, _up, _up, _up, _dp]
     L.apemost_hip_rng_raw.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32,
                                       C.POINTER(C.c_uint32)]
     L.apemost_hip_rng_attempts.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,

@@ -247,6 +247,9 @@ struct apemost_hip_sampler {
         int n_active;
         hipEvent_t ev;
         u64 segments, launches_by_waves[9];
+        double seconds_by_waves[9]; // wall time of the segments of each workgroup shape (launch to collection)
+        std::chrono::steady_clock::time_point segment_start;
+        int segment_waves;
     } cal;
     unsigned big_lds_set; // bit w: the LDS opt-in of the w-wave kernels has been made
     // APEMOST_MODEL_USER: the kernels of the user's likelihood, compiled by hiprtc at create time
@@ -716,7 +719,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->swap_pending = 0;
     s->launches = 0;
     s->launches_at_begin = 0;
-    memset(&s->cal, 0, sizeof s->cal);
+    s->cal = {};
     memset(&s->user, 0, sizeof s->user);
     s->big_lds_set = 0;
     s->stream = nullptr;
@@ -956,6 +959,12 @@ static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const
     op.coop = coop;
     op.grid = grid;
     op.lds = (kind == K_ROUND_OB || kind == K_CALIB_OB) ? ob_lds_bytes(s, lds_data) : classic_lds_bytes(s, waves, lds_data);
+    if (kind == K_CALIB && waves == 1 && !lds_data) {
+        // (experiment knob: pad the LDS request of the one-wave calibration kernel to bound how many
+        // workgroups share a CU)
+        if (const char *pad = getenv("APEMOST_CALIB_LDS_PAD"))
+            op.lds += (size_t)atol(pad);
+    }
     op.st = s->stream;
     op.args = args;
     if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
@@ -1588,6 +1597,8 @@ static int calib_launch_segment(apemost_hip_sampler *s) {
     k.in_flight = true;
     k.segments++;
     k.launches_by_waves[g.waves]++;
+    k.segment_start = std::chrono::steady_clock::now();
+    k.segment_waves = g.waves;
     return APEMOST_HIP_OK;
 }
 
@@ -1602,6 +1613,8 @@ static void calib_collect(apemost_hip_sampler *s) {
     }
     k.n_active = n;
     k.in_flight = false;
+    k.seconds_by_waves[k.segment_waves] +=
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - k.segment_start).count();
 }
 
 extern "C" int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first, int32_t count,
@@ -1654,6 +1667,8 @@ extern "C" int apemost_hip_calibrate_begin(apemost_hip_sampler *s, int32_t first
     k.cancelled = false;
     k.segments = 0;
     memset(k.launches_by_waves, 0, sizeof k.launches_by_waves);
+    for (double &t : k.seconds_by_waves)
+        t = 0;
     HIP_TRY(hipMemsetAsync(k.d_rec, 0, (size_t)count * sizeof(CalibRec), s->stream)); // stage = CAL_INIT
     HIP_TRY(hipMemsetAsync(k.d_orig, 0, (size_t)count * s->cfg.n_par * sizeof(double), s->stream));
     for (int i = 0; i < count; i++)
@@ -1808,7 +1823,7 @@ extern "C" int apemost_hip_calibrate_progress(apemost_hip_sampler *s, double *ro
 
 // segments and launches per workgroup shape of the latest calibration (bench, tests)
 extern "C" int apemost_hip_calibrate_stats(apemost_hip_sampler *s, uint64_t *segments, uint64_t *evaluations,
-                                           uint64_t launches_by_waves[9]) {
+                                           uint64_t launches_by_waves[9], double seconds_by_waves[9]) {
     CHECK_S(s);
     auto &k = s->cal;
     if (segments)
@@ -1821,6 +1836,8 @@ extern "C" int apemost_hip_calibrate_stats(apemost_hip_sampler *s, uint64_t *seg
     }
     if (launches_by_waves)
         memcpy(launches_by_waves, k.launches_by_waves, sizeof k.launches_by_waves);
+    if (seconds_by_waves)
+        memcpy(seconds_by_waves, k.seconds_by_waves, sizeof k.seconds_by_waves);
     return APEMOST_HIP_OK;
 }
 

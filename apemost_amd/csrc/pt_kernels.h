@@ -14,8 +14,9 @@ namespace apemost {
 // kernels
 // ===========================================================================
 
-// LDS carve (doubles): proposed params [2][64], wave partials [2][16], 8 control words
-constexpr int kFixedLdsDoubles = 2 * kWave + 32 + 8;
+// LDS carve (doubles): proposed params [2][64], wave partials [2][16], 8 control words, the logarithm's table
+constexpr int kLdsLogTab = 2 * kWave + 32 + 8;
+constexpr int kFixedLdsDoubles = kLdsLogTab + kLogTabLdsDoubles;
 
 struct RoundArgs {
     DevArrays d;
@@ -77,6 +78,10 @@ __device__ __forceinline__ void engine_setup(Engine<MODEL, WAVES, LDS_DATA, PROD
         *e.fail_flag() = 0; // ordered before its first use by the barrier every kernel has after setup
     if constexpr (Model<MODEL % kVariantModel>::kIndexed)
         e.m.set_data(d.data, sh.n_data, (int)((unsigned)sh.variant >> 16));
+    if constexpr (Model<MODEL % kVariantModel>::kUsesLogTable) { // (published by the barrier every kernel has after setup)
+        stage_logtab(lds + kLdsLogTab, threadIdx.x, kThreads);
+        e.m.set_logtab(lds + kLdsLogTab);
+    }
     if (d.f != nullptr) // a resident chain: its prior box may make the per-step argument check void
         e.m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
     if (LDS_DATA) {
@@ -752,12 +757,22 @@ __device__ __forceinline__ void calib_log_progress(const E &e, const CalibArgs &
     }
 }
 
+#ifndef APEMOST_CALIB_MIN_WAVES
+#define APEMOST_CALIB_MIN_WAVES(waves) ((waves) == 1 ? 2 : 1)
+#endif
+// (one-wave workgroups: at least two of them per SIMD, i.e. at most 256 registers -- the state machine
+// around the step costs the compiler a dozen registers more than the round kernel has, and a ladder of
+// 2048 chains wants both of its waves per SIMD resident)
 template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
-__global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kernel(const CalibArgs a) {
+__global__ __launch_bounds__(block_threads(WAVES, PROD)) __attribute__((amdgpu_waves_per_eu(APEMOST_CALIB_MIN_WAVES(WAVES), 8)))
+void pt_calibrate_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
-    // control word decided by wave 0, read by every wave (kept inside the dynamic
-    // region so the carve base stays 16-byte aligned)
-    volatile int &s_ctl = *(volatile int *)(lds + 2 * kWave + 32);
+    // The state machine's record lives in LDS, in the six control doubles behind the fail flag: it is
+    // looked at between blocks only, and as registers it cost the one-wave kernels their second wave
+    // per SIMD (pulse_vrot: 238 VGPRs with the record in LDS, 270 + 14 AGPRs without).  Thread 0
+    // writes it, a barrier publishes it to every wave.
+    static_assert(sizeof(CalibRec) == 6 * sizeof(double), "the record fills the control words of the LDS carve");
+    volatile CalibRec &r = *(volatile CalibRec *)(lds + 2 * kWave + 32 + 2);
     Engine<MODEL, WAVES, LDS_DATA, PROD> e;
     const int slot = a.list[blockIdx.x];
     const int c = a.first + slot;
@@ -766,81 +781,95 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kerne
     chain_load(e, a.d, a.sh, c, a.cur);
     e.pin_uniforms();
     e.producer_prologue();
+    if (e.tid == 0) {
+        const CalibRec in = a.rec[slot];
+        r.stage = in.stage, r.status = in.status, r.nchecks = in.nchecks, r.rescaled = in.rescaled;
+        r.iter = in.iter, r.sweeps = in.sweeps, r.evals = in.evals;
+        r.rat_limit = in.rat_limit;
+    }
     __syncthreads();
     e.cache_rows();
     e.producer_first_fetch();
     const bool w0 = (e.wave == 0);
     const apemost_hip_calib_config &cfg = a.cfg;
+    double *my_orig = a.orig_step + (size_t)slot * n + e.grp; // what burn_in() puts back when it ends
+    const u64 stop_at = r.evals + a.budget;
 
-    // every wave follows the state machine; what depends on the chain (rat_limit, the counters'
-    // verdicts) lives in wave 0 and reaches the others through s_ctl
-    CalibRec r = a.rec[slot];
-    double original_step = (w0 && e.cand()) ? a.orig_step[(size_t)slot * n + e.grp] : 0.0;
-    u64 done = 0;
-    while (r.stage != CAL_DONE && done < a.budget) {
-        if (r.stage == CAL_INIT) {
+    for (;;) {
+        // (every wave reads the same words: the branches below are uniform)
+        const int stage = __builtin_amdgcn_readfirstlane(r.stage);
+        if (stage == CAL_DONE || r.evals >= stop_at)
+            break;
+        int next = stage; // (what wave 0 arrives at is what counts: thread 0 writes it)
+        if (stage == CAL_INIT) {
             // ---- burn_in: src/markov_chain.c:34-79 ----
-            original_step = e.stepw;
+            if (w0 && e.cand() && e.qidx == 0)
+                *my_orig = e.stepw;
             e.stepw = (e.hi - e.lo) * 0.1;
-            r.iter = 0;
-            r.stage = CAL_BURN1;
-        } else if (r.stage == CAL_BURN1 || r.stage == CAL_BURN2) {
-            const u64 limit = r.stage == CAL_BURN1 ? cfg.burn_in_iterations / 2 : cfg.burn_in_iterations;
+            next = CAL_BURN1;
+            if (e.tid == 0)
+                r.iter = 0;
+        } else if (stage == CAL_BURN1 || stage == CAL_BURN2) {
+            const u64 limit = stage == CAL_BURN1 ? cfg.burn_in_iterations / 2 : cfg.burn_in_iterations;
             if (r.iter < limit) {
                 for (int sub = 0; sub < 200; sub++)
                     e.step(-1);
-                r.iter += 200;
-                done += 200;
                 if (w0)
                     e.check_best();
-            } else if (r.stage == CAL_BURN1) {
+                if (e.tid == 0) {
+                    r.iter += 200;
+                    r.evals += 200;
+                }
+            } else if (stage == CAL_BURN1) {
                 if (w0)
                     e.restart_from_best();
                 e.stepw *= 0.5;
-                r.stage = CAL_BURN2;
+                next = CAL_BURN2;
             } else {
-                e.stepw = original_step;
+                if (w0 && e.cand()) {
+                    __threadfence_block();
+                    e.stepw = *(volatile double *)my_orig;
+                }
                 if (a.burn_in_only) {
-                    r.stage = CAL_DONE;
+                    next = CAL_DONE;
                 } else {
                     // ---- markov_chain_calibrate_orig: src/markov_chain_calibrate.c:1039-1180 ----
-                    r.rat_limit = pow(cfg.rat_limit, 1.0 / n);
-                    r.nchecks = 0;
-                    r.sweeps = 0;
                     e.stepw *= cfg.adjust_step;
                     e.reset_accept_rejects();
-                    r.stage = CAL_SWEEP;
+                    next = CAL_SWEEP;
+                    if (e.tid == 0) {
+                        r.rat_limit = pow(cfg.rat_limit, 1.0 / n);
+                        r.nchecks = 0;
+                        r.sweeps = 0;
+                    }
                 }
             }
-        } else if (r.stage == CAL_SWEEP) {
+        } else if (stage == CAL_SWEEP) {
             for (unsigned k = 0; k < cfg.iter_readjust; k++)
                 for (int p = 0; p < n; p++) {
                     e.step(p);
                     if (w0)
                         e.check_best();
                 }
-            r.sweeps += cfg.iter_readjust;
-            done += (u64)cfg.iter_readjust * n;
-            int fail = 0;
+            next = CAL_ALL;
             if (w0) {
-                r.rescaled = calib_rescale(e, cfg, r.rat_limit, n, fail);
-                if (e.tid == 0)
-                    s_ctl = fail;
-            }
-            __syncthreads();
-            fail = s_ctl;
-            __syncthreads();
-            if (fail) {
-                r.status = 1;
-                r.stage = CAL_DONE;
-            } else {
-                if (w0) {
-                    if (r.rescaled == 0)
-                        r.nchecks++;
+                int fail = 0;
+                const int rescaled = calib_rescale(e, cfg, r.rat_limit, n, fail);
+                if (!fail) {
                     e.restart_from_best();
                     e.reset_accept_rejects();
                 }
-                r.stage = CAL_ALL;
+                if (e.tid == 0) {
+                    r.sweeps += cfg.iter_readjust;
+                    r.evals += (u64)cfg.iter_readjust * n;
+                    r.rescaled = rescaled;
+                    if (fail)
+                        r.status = 1;
+                    else if (rescaled == 0)
+                        r.nchecks += 1;
+                }
+                if (fail)
+                    next = CAL_DONE;
             }
         } else { // CAL_ALL
             for (unsigned sub = 0; sub < cfg.iter_readjust; sub++) {
@@ -848,32 +877,39 @@ __global__ __launch_bounds__(block_threads(WAVES, PROD)) void pt_calibrate_kerne
                 if (w0)
                     e.check_best();
             }
-            done += cfg.iter_readjust;
-            int ctl = 0;
+            next = CAL_SWEEP;
             if (w0) {
-                calib_log_progress(e, a, slot, r, n);
-                ctl = calib_verdict(e, cfg, r);
-                if (e.tid == 0)
-                    s_ctl = ctl;
+                CalibRec now;
+                now.nchecks = r.nchecks, now.rescaled = r.rescaled, now.sweeps = r.sweeps, now.rat_limit = r.rat_limit;
+                calib_log_progress(e, a, slot, now, n);
+                const int ctl = calib_verdict(e, cfg, now);
+                if (ctl == 1)
+                    e.reset_accept_rejects();
+                if (ctl != 0)
+                    next = CAL_DONE;
+                if (e.tid == 0) {
+                    r.evals += cfg.iter_readjust;
+                    r.rat_limit = now.rat_limit;
+                    if (ctl == 2)
+                        r.status = 2;
+                }
             }
-            __syncthreads();
-            ctl = s_ctl;
-            __syncthreads();
-            r.stage = ctl == 0 ? CAL_SWEEP : CAL_DONE;
-            if (ctl == 2)
-                r.status = 2;
-            if (ctl == 1 && w0)
-                e.reset_accept_rejects();
         }
+        // wave 0's verdicts (a failed rescaling, convergence, the iteration limit) reach the other
+        // waves through the record
+        if (e.tid == 0)
+            r.stage = next;
+        __syncthreads();
     }
     if (e.tid == 0) {
-        r.evals += done;
-        a.rec[slot] = r;
+        CalibRec out;
+        out.stage = r.stage, out.status = r.status, out.nchecks = r.nchecks, out.rescaled = r.rescaled;
+        out.iter = r.iter, out.sweeps = r.sweeps, out.evals = r.evals;
+        out.rat_limit = r.rat_limit;
+        a.rec[slot] = out;
         if (*e.fail_flag())
             st_agent(a.d.timeout_word(), 3);
     }
-    if (w0 && e.cand() && e.qidx == 0)
-        a.orig_step[(size_t)slot * n + e.grp] = original_step;
     // calibration leaves the chain in place: same half of the double buffer
     chain_store(e, a.d, a.sh, c, a.cur, true);
 }

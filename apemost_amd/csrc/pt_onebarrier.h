@@ -45,7 +45,8 @@ constexpr int kObFlag = 34;                       // [2]     != 0: a prepared pr
 constexpr int kObCtl = 36;                        // 4 control words (word 2 of the int view: Engine's fail flag slot)
 constexpr int kObProp = 40;                       // [2][2][64] proposals: [parity][0 = after accept, 1 = after reject][parameter]
 constexpr int kObCand = kObProp + 2 * 2 * kWave;  // [8][64] double2 candidate ring
-constexpr int kObFixedDoubles = kObCand + 8 * 2 * kWave;
+constexpr int kObLogTab = kObCand + 8 * 2 * kWave;  // the logarithm's table (pulse models)
+constexpr int kObFixedDoubles = kObLogTab + kLogTabLdsDoubles;
 
 // S_max of a step: accept <=> data sum < S_max.  T = prob + ln U.
 template <int MODEL>
@@ -155,6 +156,10 @@ struct ObEngine {
             *fail_flag() = 0;
             *s_flag(0) = 0;
             *s_flag(1) = 0;
+        }
+        if constexpr (Model<kBase>::kUsesLogTable) { // (published by the kernel's first barrier)
+            stage_logtab(lds + kObLogTab, (int)threadIdx.x, kBlock);
+            m.set_logtab(lds + kObLogTab);
         }
         double *s_data = lds + kObFixedDoubles;
         if (LDS_DATA) {

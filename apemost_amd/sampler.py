@@ -235,10 +235,13 @@ class HipSampler:
         return rows
 
     def calibrate_stats(self):
-        """(segments, likelihood evaluations, launches per waves-per-chain) of the latest calibration"""
+        """(segments, likelihood evaluations, launches per waves-per-chain) of the latest calibration;
+        self.calibrate_seconds_by_waves holds the wall seconds per waves-per-chain"""
         seg, ev = C.c_uint64(0), C.c_uint64(0)
         by = (C.c_uint64 * 9)()
-        capi.check(self.L.apemost_hip_calibrate_stats(self._h, C.byref(seg), C.byref(ev), by))
+        sec = (C.c_double * 9)()
+        capi.check(self.L.apemost_hip_calibrate_stats(self._h, C.byref(seg), C.byref(ev), by, sec))
+        self.calibrate_seconds_by_waves = {w: float(sec[w]) for w in range(9) if by[w]}
         return seg.value, ev.value, {w: int(by[w]) for w in range(9) if by[w]}
 
     def calibrate_first(self, cfg=None):

@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--n-data", type=int, default=None)
     ap.add_argument("--n-swap", type=int, default=None, help="0 = reference rule 2000/n_beta of the per-GPU ladder")
     ap.add_argument("--burn-in", type=int, default=None, help="BURN_IN_ITERATIONS of the device calibration")
+    ap.add_argument("--calib-iter-limit", type=int, default=None, help="ITER_LIMIT of the device calibration (experiments: a short one)")
     ap.add_argument("--flags", type=int, default=0, help="apemost_hip_config.flags")
     ap.add_argument("--rounds-per-step", type=int, default=None)
     ap.add_argument("--launches-per-step", type=int, default=None, help="batches of rounds-per-step rounds in one bench step")
@@ -189,6 +190,8 @@ def main():
         s.calc_model(0, n_local)
         s.synchronize()
         ccfg = capi.calib_defaults(burn_in_iterations=a.burn_in)
+        if a.calib_iter_limit:
+            ccfg.iter_limit = a.calib_iter_limit
         tc = time.perf_counter()
         status, iters = s.markov_chain_calibrate(0, n_local, ccfg)
         calib_wall = time.perf_counter() - tc
@@ -196,7 +199,8 @@ def main():
         calibration = calibration_block(calib_wall, status, iters, ccfg, w.n_par)
         seg, ev, by_waves = s.calibrate_stats()
         calibration.update({"segments": seg, "evaluations_counted_on_device": ev,
-                            "launches_by_waves_per_chain": {str(k): v for k, v in by_waves.items()}})
+                            "launches_by_waves_per_chain": {str(k): v for k, v in by_waves.items()},
+                            "seconds_by_waves_per_chain": {str(k): round(v, 4) for k, v in s.calibrate_seconds_by_waves.items()}})
         if a.calib_dump and rank == 0:
             json.dump({"config": a.config, "burn_in": a.burn_in, "wall_s": calib_wall, "status": status.tolist(),
                        "sweeps": [int(x) for x in iters]}, open(a.calib_dump, "w"))

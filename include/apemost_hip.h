@@ -377,9 +377,9 @@ int apemost_hip_calibrate_end(apemost_hip_sampler *s, int32_t *status, uint64_t 
  * after its k-th readjustment; rows [capacity_rows][1 + 2 n_par], *n_rows = rows that exist */
 int apemost_hip_calibrate_progress(apemost_hip_sampler *s, double *rows, int32_t capacity_rows, int32_t *n_rows);
 /* the latest calibration in numbers: segments launched, likelihood evaluations of all its chains, and
- * launches per workgroup shape (index = likelihood wavefronts per chain) */
+ * launches and wall seconds per workgroup shape (index = likelihood wavefronts per chain) */
 int apemost_hip_calibrate_stats(apemost_hip_sampler *s, uint64_t *segments, uint64_t *evaluations,
-                                uint64_t launches_by_waves[9]);
+                                uint64_t launches_by_waves[9], double seconds_by_waves[9]);
 
 /* ---- test hooks: device RNG conformance ------------------------------------ */
 /* n raw 32-bit outputs of rocRAND philox4x32_10 (seed, subsequence, offset) */

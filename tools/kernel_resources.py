@@ -2,7 +2,7 @@
 """Registers, spills, LDS and scratch per kernel, read from the gfx950 code object inside a built
 library (default: apemost_amd/libapemost_hip.so).  No GPU needed.
 
-    python tools/kernel_resources.py [lib.so] [substring of the demangled name]
+    python tools/kernel_resources.py [lib.so | object.o] [substring of the demangled name]
 
 Occupancy bound by registers on gfx950: 512 VGPRs per SIMD lane slot -> waves/SIMD =
 floor(512 / vgprs rounded up to 8), at most 8."""
@@ -49,12 +49,15 @@ def kernels(lib):
 
 def main():
     args = [a for a in sys.argv[1:]]
-    lib = os.path.join(ROOT, "apemost_amd", "libapemost_hip.so")
-    if args and args[0].endswith(".so"):
-        lib = args.pop(0)
+    # the product library is linked from one object per translation unit (apemost_amd/build.py), each
+    # with a code object of its own: read them object by object
+    obj_dir = os.path.join(ROOT, "apemost_amd", "csrc", "obj")
+    libs = sorted(os.path.join(obj_dir, f) for f in os.listdir(obj_dir) if f.endswith(".o")) if os.path.isdir(obj_dir) else []
+    if args and (args[0].endswith(".so") or args[0].endswith(".o")):
+        libs = [args.pop(0)]
     needle = args[0] if args else ""
     print("%-64s %5s %5s %5s %6s %6s %7s %8s" % ("kernel", "vgpr", "agpr", "sgpr", "vspill", "sspill", "scratch", "waves/SIMD"))
-    for k in kernels(lib):
+    for k in [k for lib in libs for k in kernels(lib)]:
         if needle not in k["demangled"]:
             continue
         v = int(k.get("vgpr_count", 0))
