@@ -207,6 +207,8 @@ struct ObEngine {
         accepted = false;
         n_accepted = 0;
         m.init_scalar();
+        if constexpr (Model<kBase>::kUsesLogTable)
+            m.set_lean(false);
         m.set_consts(consts);
         m.set_box(d.pmin() + (size_t)c * sh.n_par, d.pmax() + (size_t)c * sh.n_par, sh.x_abs_max);
     }
