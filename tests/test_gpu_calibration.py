@@ -88,11 +88,13 @@ def test_burn_in_only_matches_oracle(name, waves):
     s.close()
 
 
-@pytest.mark.parametrize("name,waves", [("simplesin", 1), ("simplesin", 4), ("pulse", 2), ("sine3", 8)])
+@pytest.mark.parametrize("name,waves", [("simplesin", 1), ("simplesin", 4), ("pulse", 2), ("sine3", 8), ("pulse", 1), ("pulse_vrot", 1)])
 def test_launch_round_for_matches_oracle_step_for(name, waves):
     """apemost_hip_launch_round_for = n x markov_chain_step_for(m, p): only parameter p moves, only
     its counters count, m->accept / m->reject stay (quirk Q5); what the host layer's
-    markov_chain_step_for() calls"""
+    markov_chain_step_for() calls.  The one-wave kernels of the pulse models take single-parameter
+    updates of the additive parameter (p = 1) without walking the data vector (Engine::kOffsetShortcut):
+    the rows must be the oracle's all the same."""
     import torch
     w = small_workloads()[name]
     n_chain = 6
