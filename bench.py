@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--calib-dump", default=None, help="write the calibration's per-chain status and sweep counts (JSON)")
     ap.add_argument("--maps-dump", default=None, help="debug: write /proc/self/maps there before exiting (to assign the "
                                                       "addresses of a native stack trace to libraries)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --same-device rehearses the N > 1 path on a one-GPU box "
+                         "(RCCL refuses two ranks on one device)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal of N > 1 on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even with one rank")
     a = ap.parse_args()
     for k, v in CONFIGS[a.config].items():
@@ -155,12 +159,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_dist
+    comm_device = "cuda" if a.backend == "nccl" else "cpu"   # where the bench's own small collectives live
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n_local = a.chains_per_gpu
     n_global = n_local * world
@@ -242,10 +252,10 @@ def main():
     dt = time.perf_counter() - t0
     per_rank = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine = torch.tensor([dt_rank, float(ladder.exchanges)], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([dt_rank, float(ladder.exchanges)], dtype=torch.float64, device=comm_device)
         every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)
         per_rank = np.array([e.cpu().numpy() for e in every])
