@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -430,6 +431,8 @@ struct HipRtc {
 
 static int hiprtc_load(HipRtc &r) {
     static HipRtc cached = {};
+    static std::mutex once;
+    std::lock_guard<std::mutex> hold(once); // (samplers may be created from several host threads)
     if (!cached.lib) {
         const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
         for (const char *n : names)
