@@ -962,12 +962,6 @@ static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const
     op.coop = coop;
     op.grid = grid;
     op.lds = (kind == K_ROUND_OB || kind == K_CALIB_OB) ? ob_lds_bytes(s, lds_data) : classic_lds_bytes(s, waves, lds_data);
-    if (kind == K_CALIB && waves == 1 && !lds_data) {
-        // (experiment knob: pad the LDS request of the one-wave calibration kernel to bound how many
-        // workgroups share a CU)
-        if (const char *pad = getenv("APEMOST_CALIB_LDS_PAD"))
-            op.lds += (size_t)atol(pad);
-    }
     op.st = s->stream;
     op.args = args;
     if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
