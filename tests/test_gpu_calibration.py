@@ -344,11 +344,11 @@ def test_calibration_can_be_polled_and_cancelled(monkeypatch):
 
 
 def test_data_vector_between_the_two_kernels_lds_limits_is_staged_correctly():
-    """n_data = 3300 with the data vector forced into LDS: 12608 + 52800 B for the two-phase kernels is
-    under 64 KiB, 13632 + 52800 B for the one-barrier kernels is over it, so only the latter need the
+    """n_data = 3100 with the data vector forced into LDS: 15680 + 49600 B for the two-phase kernels is
+    under 64 KiB, 16704 + 49600 B for the one-barrier kernels is over it, so only the latter need the
     opt-in for large dynamic LDS (the opt-in was decided on the two-phase footprint alone)"""
     import torch
-    w = wl.simplesin(n_data=3300, n_chain=8)
+    w = wl.simplesin(n_data=3100, n_chain=8)
     n_chain = 8
     st, lad, rng = make_pair(w, n_chain, seed=3, init_prob=True)
     s = HipSampler(w.model, 4, n_chain, w.data, seed=3, waves_per_chain=4, lds_policy=1)
@@ -358,7 +358,7 @@ def test_data_vector_between_the_two_kernels_lds_limits_is_staged_correctly():
     s.run_sampler(3, 9, d.data_ptr())
     s.synchronize()
     ref = orc.run_sampler(lad, rng, 3, 9, record=True)
-    assert_match(s.get_state(), lad, rng, what="n_data 3300 in LDS")
+    assert_match(s.get_state(), lad, rng, what="n_data 3100 in LDS")
     np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-9)
     dcfg, ocfg = _cfgs(burn=200)
     status, iters = s.markov_chain_calibrate(0, 2, dcfg)
