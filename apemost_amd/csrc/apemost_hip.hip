@@ -479,6 +479,29 @@ static void source_dirs(std::string &csrc, std::string &inc) {
     inc = e2 ? e2 : dir + "/../include";
 }
 
+// a compiled user model: the code object and the lowered names of its four kernels.  Kept per process
+// and keyed by (source text, kernel variant, device architecture): a host creates several samplers per
+// phase (the one that checks the device model against the host plugin, one per shard, the one-chain
+// twin of the single-chain API) and compiles once.
+namespace {
+struct UserModelCode {
+    std::string key;
+    std::vector<char> code;
+    std::string lowered[4];
+};
+std::vector<UserModelCode> g_user_models;
+std::mutex g_user_models_lock;
+} // namespace
+
+static int user_model_load(apemost_hip_sampler *s, const UserModelCode &m) {
+    HIP_TRY(hipModuleLoadData(&s->user.module, m.code.data()));
+    HIP_TRY(hipModuleGetFunction(&s->user.round, s->user.module, m.lowered[0].c_str()));
+    HIP_TRY(hipModuleGetFunction(&s->user.calibrate, s->user.module, m.lowered[1].c_str()));
+    HIP_TRY(hipModuleGetFunction(&s->user.calc_model, s->user.module, m.lowered[2].c_str()));
+    HIP_TRY(hipModuleGetFunction(&s->user.loglike, s->user.module, m.lowered[3].c_str()));
+    return APEMOST_HIP_OK;
+}
+
 static int user_model_build(apemost_hip_sampler *s) {
     HipRtc rtc;
     int rc = hiprtc_load(rtc);
@@ -509,6 +532,15 @@ static int user_model_build(apemost_hip_sampler *s) {
         rtc.add_name(prog, n);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->cfg.device));
+    const std::string key = std::to_string(s->kmodel) + "|" + prop.gcnArchName + "|" + user;
+    {
+        std::lock_guard<std::mutex> hold(g_user_models_lock);
+        for (const UserModelCode &m : g_user_models)
+            if (m.key == key) {
+                rtc.destroy(&prog);
+                return user_model_load(s, m);
+            }
+    }
     const std::string arch = std::string("--offload-arch=") + prop.gcnArchName, i1 = "-I" + csrc, i2 = "-I" + inc;
     const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", i1.c_str(), i2.c_str(), "-I/opt/rocm/include"};
     const hiprtcResult cr = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
@@ -521,26 +553,27 @@ static int user_model_build(apemost_hip_sampler *s) {
         rtc.destroy(&prog);
         return fail(APEMOST_HIP_ERR_INVALID, "device model %s does not compile:\n%.400s", s->cfg.device_model_source, log.c_str());
     }
+    UserModelCode m;
+    m.key = key;
     size_t code_bytes = 0;
     rtc.code_size(prog, &code_bytes);
-    std::vector<char> code(code_bytes);
-    rtc.code(prog, code.data());
-    std::string lowered[4];
+    m.code.resize(code_bytes);
+    rtc.code(prog, m.code.data());
     for (int i = 0; i < 4; i++) {
         const char *low = nullptr;
         if (rtc.lowered(prog, names[i], &low) != HIPRTC_SUCCESS || !low) {
             rtc.destroy(&prog);
             return fail(APEMOST_HIP_ERR_RUNTIME, "hiprtcGetLoweredName(%s) failed", names[i]);
         }
-        lowered[i] = low;
+        m.lowered[i] = low;
     }
     rtc.destroy(&prog);
-    HIP_TRY(hipModuleLoadData(&s->user.module, code.data()));
-    HIP_TRY(hipModuleGetFunction(&s->user.round, s->user.module, lowered[0].c_str()));
-    HIP_TRY(hipModuleGetFunction(&s->user.calibrate, s->user.module, lowered[1].c_str()));
-    HIP_TRY(hipModuleGetFunction(&s->user.calc_model, s->user.module, lowered[2].c_str()));
-    HIP_TRY(hipModuleGetFunction(&s->user.loglike, s->user.module, lowered[3].c_str()));
-    return APEMOST_HIP_OK;
+    rc = user_model_load(s, m);
+    if (rc == APEMOST_HIP_OK) {
+        std::lock_guard<std::mutex> hold(g_user_models_lock);
+        g_user_models.push_back(std::move(m));
+    }
+    return rc;
 }
 
 // the part of apemost_hip_create that can fail after the sampler object exists
