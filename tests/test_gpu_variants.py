@@ -151,3 +151,49 @@ def test_variant_flags_are_validated():
         HipSampler(w.model, w.n_par, 4, w.data, flags=capi.FLAG_RANDOMSWAP, waves_per_chain=6)
     with pytest.raises(capi.ApemostHipError, match="adapt_target"):
         HipSampler(w.model, w.n_par, 4, w.data, flags=capi.FLAG_ADAPT, adapt_target=-1.0)
+
+
+def test_samples_packed_on_the_device_equal_the_rows_repacked_on_the_host():
+    """apemost_hip_samples_pack_read_async: the record of the C host's binary sink (layout 0: the
+    parameter vectors of the first n_param_chains chains, then (prob, prob - prior) of every chain)
+    and thinned rows (layout 1), for every skip / thin / n_param_chains combination tried, against
+    numpy on the rows read back whole"""
+    import ctypes as C
+    import torch
+    from apemost_amd import capi, workloads as wl
+    from apemost_amd.sampler import HipSampler
+    from tests.helpers import make_pair
+    n_chain, n_steps = 5, 37
+    w = wl.pulse(n_data=64, n_chain=n_chain)
+    st, _, _ = make_pair(w, n_chain, seed=8, init_prob=True)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=8)
+    s.set_state(st)
+    npar = w.n_par
+    rows = torch.zeros((n_steps, n_chain, npar + 2), dtype=torch.float64, device="cuda")
+    s.launch_round(n_steps, False, rows.data_ptr())
+    s.synchronize()
+    ref = rows.cpu().numpy()
+    L = s.L
+    host = C.c_void_p()
+    capi.check(L.apemost_hip_host_alloc(ref.nbytes, C.byref(host)))
+    packed = torch.zeros(ref.size, dtype=torch.float64, device="cuda")
+    counters = np.zeros(2 * n_chain, dtype=np.uint64)
+    for layout, npc, skip, thin in ((0, 1, 0, 1), (0, n_chain, 2, 5), (0, 0, 36, 40), (0, 3, 0, 7), (1, 0, 0, 1), (1, 0, 4, 9), (1, 0, 37, 3)):
+        kept = C.c_uint64(0)
+        capi.check(L.apemost_hip_samples_pack_read_async(s._h, rows.data_ptr(), n_steps, skip, thin, npc, layout, packed.data_ptr(),
+                                                         host, counters.ctypes.data_as(C.c_void_p), C.byref(kept)))
+        capi.check(L.apemost_hip_samples_wait(s._h))
+        steps = list(range(skip, n_steps, thin))
+        assert kept.value == len(steps)
+        if layout == 0:
+            want = np.array([np.concatenate([ref[k, :npc, :npar].ravel(), ref[k, :, npar:].ravel()]) for k in steps]).ravel()
+        else:
+            want = ref[steps].ravel()
+        got = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_double)), shape=(ref.size,))[:want.size]
+        assert np.array_equal(got, want), (layout, npc, skip, thin)
+        dev = s.get_state()
+        assert np.array_equal(counters[:n_chain], dev.accept) and np.array_equal(counters[n_chain:], dev.reject)
+    assert L.apemost_hip_samples_pack_read_async(s._h, rows.data_ptr(), n_steps, 0, 0, 0, 0, packed.data_ptr(), host, None,
+                                                 None) == capi.ERR_INVALID          # thin 0
+    capi.check(L.apemost_hip_host_free(host))
+    s.close()

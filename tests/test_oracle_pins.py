@@ -318,3 +318,48 @@ def test_adapt_thresholds_and_scaling():
     assert np.array_equal(lad.step[3], step0[3])
     assert lad.params_accepts[3].sum() == 0 and lad.params_rejects[3].sum() == 0 and lad.accept[3] == lad.reject[3] == 0
     assert lad.params_accepts[1].sum() == 6000      # below 100000: kept
+
+
+# ---- the reference's other example likelihoods (checkers of the user-supplied device models) -------------
+def test_oracle_restatements_of_the_other_example_apps_against_numpy():
+    """ll_sine2 / ll_normal / ll_bernoulli of the oracle (apps/simplesin2.c:12-34, apps/normal.c:8-34,
+    apps/bernoulli_example.c:10-49) against the same formulas written independently in numpy, with the
+    serial left-to-right sums of the C loops"""
+    rs = np.random.RandomState(11)
+    # simplesin2: beta * sum (A sin(2 pi (f x + 0.3312)) - y)^2 / (-2 sigma^2)
+    d = np.stack([100 + 0.5 * np.arange(40), rs.normal(0, 1, 40)], 1)
+    for A, f, beta in ((0.8, 0.21, 1.0), (1.7, 0.05, 0.3)):
+        want = 0.0
+        for x, y in d:
+            r = A * np.sin(2.0 * np.pi * (f * x + 0.3312)) - y
+            want += r * r
+        want = beta * want / (-2 * 0.5 * 0.5)
+        got, prior = orc.loglike(orc.MODEL_SINE2, np.array([A, f]), d, beta=beta)
+        assert abs(got - want) <= 1e-13 * abs(want) and prior == 0.0
+    # normal: beta * max over ten peaks (even: Gaussian-like, odd: triangular), floor 0
+    for x, beta in ((3.0, 1.0), (150.0, 0.5), (8000.0, 0.2), (0.4, 1.0)):
+        b = 0.0
+        for i in range(10):
+            pos, height, sigma = np.exp(i), 10 * 1.0 ** i, float(i)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if i % 2 == 0:
+                    a = -sigma * ((x - pos) / sigma) ** 2 / 2 + height if sigma else np.nan
+                else:
+                    a = -height * abs(x - pos) / sigma + height
+            if a > b:
+                b = a
+        got, _ = orc.loglike(orc.MODEL_NORMAL, np.array([x]), d, beta=beta)
+        assert abs(got - beta * b) <= 1e-13 * max(abs(beta * b), 1.0), (x, got, beta * b)
+    # bernoulli: prior = sum_j>=1 -(p_j / 2)^2 / 2; prob = prior + beta * sum_i log(p_i or 1 - p_i)
+    X = rs.normal(0, 1, (30, 2))
+    out = (rs.uniform(size=30) < 0.5).astype(float)
+    data = np.column_stack([out, X])
+    for p, beta in ((np.array([0.3, 1.1, -0.7]), 1.0), (np.array([-1.0, 0.2, 2.5]), 0.4)):
+        prior = sum(-(pj / 2) ** 2 / 2 for pj in p[1:])
+        s = 0.0
+        for row in data:
+            eta = p[0] + row[1] * p[1] + row[2] * p[2]
+            pi = 1 / (1 + np.exp(-eta)) if eta > 0 else np.exp(eta) / (1 + np.exp(eta))
+            s += np.log(1 - pi) if row[0] == 0 else np.log(pi)
+        got, got_prior = orc.loglike(orc.MODEL_BERNOULLI, p, data, beta=beta)
+        assert abs(got_prior - prior) <= 1e-15 and abs(got - (prior + beta * s)) <= 1e-13 * abs(prior + beta * s)
