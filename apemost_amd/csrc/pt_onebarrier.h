@@ -330,37 +330,39 @@ struct ObEngine {
     // the wave's share of sum_i term(x_i, y_i) at the loaded parameters (Engine::reduce_data's loops)
     __device__ __forceinline__ double lik_partial() {
         double acc = 0;
+        LogProd lp; // (kLogProduct models: the lane's prod y; unused otherwise)
+        lp.init();
         int i = tid;
         if (rows_in_regs) {
-            double tw[kWide];
-            m.template terms<kWide, kShortChain>(row_x, row_y, tw);
-#pragma unroll
-            for (int j = 0; j < kWide; j++)
-                acc += tw[j];
+            add_terms<kWide, kShortChain, false>(m, row_x, row_y, acc, lp);
             i = n_data;
         }
         if (LW < 8) {
             for (; i + 3 * kLikThreads < n_data; i += 4 * kLikThreads) {
                 const double x4[4] = {xs[i], xs[i + kLikThreads], xs[i + 2 * kLikThreads], xs[i + 3 * kLikThreads]};
                 const double y4[4] = {ys[i], ys[i + kLikThreads], ys[i + 2 * kLikThreads], ys[i + 3 * kLikThreads]};
-                double t4[4];
-                m.template terms<4, kShortChain>(x4, y4, t4);
-                acc += t4[0];
-                acc += t4[1];
-                acc += t4[2];
-                acc += t4[3];
+                add_terms<4, kShortChain, false>(m, x4, y4, acc, lp);
+                if constexpr (Model<kBase>::kLogProduct)
+                    lp.renorm();
             }
         }
         for (; i + kLikThreads < n_data; i += 2 * kLikThreads) {
             const double x2[2] = {xs[i], xs[i + kLikThreads]};
             const double y2[2] = {ys[i], ys[i + kLikThreads]};
-            double t2[2];
-            m.template terms<2, kShortChain>(x2, y2, t2);
-            acc += t2[0];
-            acc += t2[1];
+            add_terms<2, kShortChain, false>(m, x2, y2, acc, lp);
+            if constexpr (Model<kBase>::kLogProduct)
+                lp.renorm();
         }
-        for (; i < n_data; i += kLikThreads)
-            acc += m.term(xs[i], ys[i]);
+        for (; i < n_data; i += kLikThreads) {
+            if constexpr (Model<kBase>::kLogProduct) {
+                const double x1[1] = {xs[i]}, y1[1] = {ys[i]};
+                add_terms<1, kShortChain, false>(m, x1, y1, acc, lp);
+                lp.renorm();
+            } else
+                acc += m.term(xs[i], ys[i]);
+        }
+        if constexpr (Model<kBase>::kLogProduct)
+            acc += lp.template finish<false>(m.tab);
         return wave_reduce_sum_lane63(acc); // valid in lane 63
     }
 
