@@ -330,7 +330,7 @@ struct ObEngine {
     // the wave's share of sum_i term(x_i, y_i) at the loaded parameters (Engine::reduce_data's loops)
     __device__ __forceinline__ double lik_partial() {
         double acc = 0;
-        LogProd lp; // (kLogProduct models: the lane's prod y; unused otherwise)
+        typename Model<kBase>::LogAcc lp; // (kLogProduct models: the lane's prod y; unused otherwise)
         lp.init();
         int i = tid;
         if (rows_in_regs) {
