@@ -87,7 +87,7 @@ struct ObEngine {
     static constexpr int kProducers = 3;
     static constexpr int kBlock = (LW + 1 + kProducers) * kWave;
     static constexpr int kWide = LW < 8 ? 4 : 2;
-    static constexpr bool kShortChain = LW >= APEMOST_SHORT_CHAIN_WAVES;
+    static constexpr int kShortChain = LW >= APEMOST_SHORT_CHAIN_WAVES ? 1 : LW >= APEMOST_EVEN_ODD_WAVES ? 2 : 0;
     static constexpr bool kVariants = MODEL >= kVariantModel; // see kVariantModel (pt_device.h)
     static constexpr int kBase = MODEL % kVariantModel;
     static constexpr bool kSine = kBase == APEMOST_MODEL_SIMPLESIN || kBase == APEMOST_MODEL_SINE3;
@@ -354,11 +354,13 @@ struct ObEngine {
                 lp.renorm();
         }
         for (; i < n_data; i += kLikThreads) {
+            const double x1[1] = {xs[i]}, y1[1] = {ys[i]};
             if constexpr (Model<kBase>::kLogProduct) {
-                const double x1[1] = {xs[i]}, y1[1] = {ys[i]};
                 add_terms<1, kShortChain, false>(m, x1, y1, acc, lp);
                 lp.renorm();
-            } else
+            } else if constexpr (Model<kBase>::kFusedAcc)
+                add_terms<1, kShortChain, false>(m, x1, y1, acc, lp);
+            else
                 acc += m.term(xs[i], ys[i]);
         }
         if constexpr (Model<kBase>::kLogProduct)
