@@ -334,7 +334,7 @@ __device__ __forceinline__ void swap_in_launch(E &e, const DevArrays &d, const C
 
 // (the pulse model's one-wave kernel sits at the edge of three resident waves per SIMD, 168 registers:
 // ladders of 1500+ chains run 2048: 1.29 vs 1.54e8 steps/s with two)
-constexpr int round_min_waves(int model, int waves) { return model % kVariantModel == APEMOST_MODEL_PULSE && waves == 1 ? 3 : 1; }
+constexpr int round_min_waves(int model, int waves) { return model % kVariantModel == APEMOST_MODEL_PULSE && waves == 1 ? APEMOST_PULSE_MIN_WAVES : 1; }
 template <int MODEL, int WAVES, bool LDS_DATA, bool PROD>
 __global__ __launch_bounds__(block_threads(WAVES, PROD)) __attribute__((amdgpu_waves_per_eu(round_min_waves(MODEL, WAVES), 8)))
 void pt_round_kernel(const RoundArgs a) {
