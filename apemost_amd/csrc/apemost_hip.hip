@@ -349,15 +349,18 @@ static int choose_waves(const apemost_hip_config &c) {
     // chains -- two waves per SIMD with the owner and the producers, no likelihood wave waits for a
     // sibling on its SIMD -- and eight only where a step is long enough to be bound by issue rather
     // than by the chain of dependent operations (>= 8192 points at <= 128 chains).
-    // The pulse likelihood -- a loop over the modes that reads its parameters from LDS as it goes, a
-    // longer chain per point than the others -- is the exception: eight waves up to 256 chains
-    // (256 x 1024: 1.51 vs 1.41e8, 128 x 1024: 9.0 vs 8.2e7; pulse_vrot and sine3 stay with four:
-    // 8.9 vs 8.4e7 and 1.05 vs 1.03e8 at 128 x 1024; tools/gpu_exp_w8.sh).
+    // The pulse likelihood with more than three modes -- a loop over the modes that reads its parameters
+    // from LDS as it goes, a longer chain per point than the others -- is the exception: eight waves up
+    // to 256 chains (256 x 1024: 1.51 vs 1.41e8, 128 x 1024: 9.0 vs 8.2e7 in round 2; pulse_vrot and
+    // sine3 stay with four: 8.9 vs 8.4e7 and 1.05 vs 1.03e8 at 128 x 1024; tools/gpu_exp_w8.sh).  Up
+    // to three modes the spectrum is taken over a common denominator since round 3 (16 instead of 46
+    // instructions per point) and four waves do more: 64 / 128 / 256 / 512 x 1024 5.14 / 11.2 / 23.6 /
+    // 35.5e7 against 5.01 / 10.9 / 21.5 / 4.8e7 with eight (profiles/r03_pulse_waves.txt).
     // Two waves per chain only while such a ladder is still resident (three or four two-wave
     // workgroups per CU: up to 768 chains; 700 x 1024: 2.55 vs 2.46e8); beyond that a launch would
     // hold one round and one wave per chain does more (900 x 1024: 3.11 vs 1.68e8).
     int by_chip = (c.n_chains <= 128 && c.n_data >= 8192) ? 8 : c.n_chains <= 512 ? 4 : c.n_chains <= 768 ? 2 : 1;
-    if (c.model == APEMOST_MODEL_PULSE && c.n_chains <= 256)
+    if (c.model == APEMOST_MODEL_PULSE && c.n_chains <= 256 && c.n_par > 8)
         by_chip = 8;
     // never fewer than 2 data points per lane
     int by_data = 1;

@@ -599,32 +599,37 @@ def test_circular_parameters_wrap_like_the_reference():
     s.close()
 
 
+@pytest.mark.parametrize("waves", [0, 8])
 @pytest.mark.parametrize("flags", [0, capi.FLAG_RANDOMSWAP])
-def test_config4_shard_kernel_as_the_bench_launches_it_matches_oracle(flags):
+def test_config4_shard_kernel_as_the_bench_launches_it_matches_oracle(flags, waves):
     """BASELINE config 4 as one GPU of eight sees it and as bench.py --config 4 launches it: pulse,
-    256 chains x 1024 points, the geometry the engine chooses by itself (eight likelihood waves + owner
-    + three producers per chain, the data vector in LDS), n_swap 1 -- every step is a round, so the
+    256 chains x 1024 points, the geometry the engine chooses by itself (waves 0: four likelihood waves
+    + owner + three producers per chain since the pulse spectrum is taken over a common denominator,
+    the data vector in LDS; eight likelihood waves, the engine's choice of round 2 and still its choice
+    for more than three modes, asked for by name), n_swap 1 -- every step is a round, so the
     pipeline of prepared proposals runs through round boundaries that are none and restarts only for
     the two chains of a swap attempt --, 256 rounds in ONE launch placed by hipLaunchCooperativeKernel
-    (256 twelve-wave workgroups fit the occupancy figure, one per CU, but not the engine's cautious
-    estimate), the pulse prior computed one logarithm per lane.  Against the oracle: counters, ticks
-    and swap counts bit-exact, every recorded row to 1e-9; the same under -DRANDOMSWAP."""
+    (256 workgroups fit the occupancy figure but not the engine's cautious estimate), the pulse prior
+    computed one logarithm per lane.  Against the oracle: counters, ticks and swap counts bit-exact,
+    every recorded row to 1e-9; the same under -DRANDOMSWAP."""
     torch = _torch()
     n_chain, n_rounds = 256, 256
     w = wl.pulse(n_data=1024, n_chain=n_chain)
     st, lad, rng = make_pair(w, n_chain, seed=404, init_prob=True)
     lad.randomswap = 1 if flags & capi.FLAG_RANDOMSWAP else 0
-    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=404, flags=flags)
-    assert s.geometry == (8, True)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=404, flags=flags, waves_per_chain=waves)
+    assert s.geometry == (waves or 4, True)
     one_barrier, cooperative, max_rounds = s.launch_policy
-    assert one_barrier and cooperative and max_rounds >= n_rounds
+    # (256 eight-wave workgroups are resident by the engine's own estimate, two per CU; the twelve-wave
+    # ones go through the runtime's placement)
+    assert one_barrier and cooperative == (waves == 8) and max_rounds >= n_rounds
     s.set_state(st)
     d = torch.zeros((n_rounds, 1, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
     before = s.round[0]
     s.launch_rounds(n_rounds, 1, False, d.data_ptr())          # one launch, as one bench step
     s.launch_round(0, True)                                     # the swap attempt that closes the last round
     s.synchronize()
-    assert s.launch_policy[1] and s.round[0] - before == n_rounds   # the runtime placed the grid; nothing was re-issued
+    assert s.launch_policy[1] == cooperative and s.round[0] - before == n_rounds   # nothing was re-issued
     dev = s.get_state()
     ref = orc.run_sampler(lad, rng, n_rounds, 1, record=True, n_threads=8)
     assert_match(dev, lad, rng, what="config-4 shard kernel flags=%d" % flags)
