@@ -537,6 +537,9 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
             }
             for (unsigned s = 0; s < a.n_steps; s++) {
                 OB_STAMP_BEGIN;
+#ifdef APEMOST_STAMPS
+                e.seg_last = ob_t0;
+#endif
                 // one batch of LDS reads: the redraw flag, what the prepared proposals settled on
                 // for my parameter, and (owner_results) the partial sums
                 const int pending = *e.s_flag(p);
@@ -568,8 +571,12 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
         }
         OB_STAMP_FLUSH;
 #ifdef APEMOST_STAMPS
-        if (blockIdx.x == 0 && e.lane == 0)
+        if (blockIdx.x == 0 && e.lane == 0) {
             atomicAdd(&g_stamps[15], ob_total);
+            if (LW == 4) // (slots 8..13 are free with eight waves per workgroup)
+                for (int i = 0; i < 6; i++)
+                    atomicAdd(&g_stamps[8 + i], e.seg_acc[i]);
+        }
 #endif
         e.owner_settle_counters((u64)a.n_steps * a.n_rounds);
         if (e.lane == 0)

@@ -81,8 +81,28 @@ struct ObThreshold<APEMOST_MODEL_PULSE> {
 template <>
 struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> {};
 
+// Diagnostic build (-DAPEMOST_STAMPS): the owner's step in segments, s_memtime ticks between the points it
+// reaches (workgroup 0; g_stamps[LW + 4 ...], tools/ob_profile.py).  A point is reached when everything
+// before it has issued, waits for operands included.
+#ifdef APEMOST_STAMPS
+#define OB_SEG(i)                                                                                 \
+    do {                                                                                          \
+        const u64 now__ = __builtin_amdgcn_s_memtime();                                           \
+        seg_acc[i] += now__ - seg_last;                                                           \
+        seg_last = now__;                                                                         \
+    } while (0)
+#else
+#define OB_SEG(i)                                                                                 \
+    do {                                                                                          \
+    } while (0)
+#endif
+
 template <int MODEL, int LW, bool LDS_DATA>
 struct ObEngine {
+#ifdef APEMOST_STAMPS
+    u64 seg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 seg_last = 0;
+#endif
     static constexpr int kLikThreads = LW * kWave;
     static constexpr int kProducers = 3;
     static constexpr int kBlock = (LW + 1 + kProducers) * kWave;
@@ -521,6 +541,7 @@ struct ObEngine {
     __device__ __forceinline__ void owner_results(int parity, double *sample, int which = -1, bool check_best = true) {
         const double sum = tree(parity);
         accepted = sum < thr;
+        OB_SEG(0); // LDS batch, partial sums, decision
         // (the proposal's prior was computed for its threshold, a step ago: not again)
         const double prob_new = m.finish_known_prior(sum, beta_all, consts, prior_inflight);
         if (Model<kBase>::kHasPrior)
@@ -551,6 +572,7 @@ struct ObEngine {
         }
         cand_y = next_y; // the kernel's loop has advanced `tick` to the step now in flight
         cand_s = next_s;
+        OB_SEG(1); // finish, counters, best point, sample row
     }
 
     // the step now in flight proposes s_prop(parity, variant): settle it (redraw path if the
@@ -568,6 +590,7 @@ struct ObEngine {
             par_val = cand() ? row[grp] : 0.0;
         }
         m.load(row, n_par, x_abs_max);
+        OB_SEG(2); // the proposal in flight
     }
     __device__ __forceinline__ void owner_publish(int parity, int which_next = -1) {
         const int next = parity ^ 1;
@@ -578,17 +601,20 @@ struct ObEngine {
         // the two proposals of the next step: from the proposal in flight, from the current point
         fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0), which_next);
         fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
+        OB_SEG(3); // next candidates, both prepared proposals
         // S_max of the step in flight
         double prior_new = 0;
         if (Model<kBase>::kHasPrior)
             prior_new = m.prior_only(consts);
         prior_inflight = prior_new;
+        OB_SEG(4); // the prior of the proposal in flight
         const double lu = read_lane(cand_y, 63);
         thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());
         if (lane == 0) {
             *s_thr(next) = thr;
             *s_flag(next) = (fail_a | fail_r) != 0 ? 1 : 0;
         }
+        OB_SEG(5); // threshold, flags
     }
     // first thing after the barrier, in one batch with the partial sums: what each prepared proposal
     // settled on for my parameter

@@ -89,6 +89,39 @@ def test_loglike_matches_oracle(name, waves):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["pulse", "pulse_vrot"])
+def test_pulse_loglike_over_a_wide_range_of_units(name):
+    """The pulse likelihoods take sum ln y as the logarithm of a running product split into mantissa and
+    exponent, and the quotients d / y two points at a time over a common denominator (pt_device.h
+    LogProdT, terms_lp): products of pairs of numerators and denominators must stay inside fp64's range.
+    The same spectrum in other units -- frequencies in units 1e6 times smaller or larger (the lifetime
+    scaled with them), heights and data 1e60 times smaller or larger -- against the oracle, which adds a
+    gsl_sf_log per point: 1e-12 as everywhere, ragged length, one and four waves per chain."""
+    w = small_workloads()[name]
+    rs = np.random.RandomState(5)
+    base = w.pmin + (w.pmax - w.pmin) * rs.uniform(0.2, 0.8, size=(5, w.n_par))
+    beta = rs.uniform(0.05, 1.0, len(base))
+    heights = [3, 5] if name == "pulse" else [4, 6]
+    freqs = [2, 4] if name == "pulse" else [2, 3, 5]                  # (pulse_vrot: vrot, fa, fb)
+    for sf in (1e-6, 1.0, 1e6):
+        for sh in (1e-60, 1.0, 1e60):
+            data = w.data[:301].copy()
+            data[:, 0] *= sf
+            data[:, 1] *= sh
+            params = base.copy()
+            params[:, 0] /= sf                                         # lifetime: 2 pi (f - nu) tau keeps its value
+            params[:, freqs] *= sf
+            params[:, heights] *= sh
+            for waves in (1, 4):
+                s = HipSampler(w.model, w.n_par, 2, data, waves_per_chain=waves)
+                prob, prior = s.loglike(params, beta)
+                ref = [orc.loglike(w.model, params[i], data, beta=beta[i]) for i in range(len(params))]
+                assert np.all(np.isfinite(prob)), (sf, sh, waves)
+                np.testing.assert_allclose(prob, [r[0] for r in ref], rtol=1e-12, err_msg="%g %g %d" % (sf, sh, waves))
+                np.testing.assert_allclose(prior, [r[1] for r in ref], rtol=1e-13, atol=1e-300)
+                s.close()
+
+
 def test_loglike_ragged_and_tiny_inputs():
     # n_data not a multiple of the wavefront, and smaller than one wavefront
     for n_data in (1, 3, 63, 65, 1000):

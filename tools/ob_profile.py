@@ -42,6 +42,12 @@ def main():
     for hw in range(waves + 4):
         role = "likelihood" if hw < waves else "owner" if hw == waves else "producer"
         print("   wave %2d %-10s busy %7.0f" % (hw, role, out[hw] / n_steps))
+    if waves == 4:
+        names = ["LDS batch, partial sums, decision", "finish, counters, best point, sample row", "the proposal in flight (choose)",
+                 "next candidates, both prepared proposals", "the prior of the proposal in flight", "threshold, flags"]
+        print("   the owner's step in segments (ticks between the points it reaches):")
+        for i, nm in enumerate(names):
+            print("      %-45s %7.0f" % (nm, out[8 + i] / n_steps))
     s.close()
 
 
