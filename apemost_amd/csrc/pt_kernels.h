@@ -440,7 +440,7 @@ __device__ __forceinline__ u64 rounds_restarting(const E &e, const RoundArgs &a,
 }
 
 template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(4))) void pt_round_ob_kernel(const RoundArgs a) {
+__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_round_ob_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA> e;
     const int c = blockIdx.x;
@@ -543,6 +543,9 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
                 // one batch of LDS reads: the redraw flag, what the prepared proposals settled on
                 // for my parameter, and (owner_results) the partial sums
                 const int pending = *e.s_flag(p);
+#if APEMOST_HOIST_CAND
+                const double2 nx = e.owner_fetch_next_cand(); // (with the step's first batch of LDS reads)
+#endif
                 if (open) {
                     e.owner_fetch_selected(p);
                     e.owner_results(p, my_sample);
@@ -553,7 +556,10 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
                 e.owner_choose(p, !open);
                 if (redraw_pending) // rare: a proposal in LDS has just been replaced
                     __syncthreads();
-                e.owner_publish(p);
+#if !APEMOST_HOIST_CAND
+                const double2 nx = e.owner_fetch_next_cand();
+#endif
+                e.owner_publish(p, nx);
                 e.tick++;
                 OB_STAMP_END;
                 __syncthreads();
@@ -934,7 +940,7 @@ void pt_calibrate_kernel(const CalibArgs a) {
 // parameter vectors as ever.  The proposal of parameter p+1 does not depend on the outcome of
 // parameter p's step, only the rest of the vector does, so both variants carry the same attempt.
 template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(4))) void pt_calibrate_ob_kernel(const CalibArgs a) {
+__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_calibrate_ob_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA> e;
     const int slot = a.list[blockIdx.x];
@@ -1041,6 +1047,9 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
             int which_prev = -1;         // ... and what the step in flight proposed
             for (int s = 0; s < n_steps; s++) {
                 const int pending = *e.s_flag(p);
+#if APEMOST_HOIST_CAND
+                const double2 nx = e.owner_fetch_next_cand();
+#endif
                 if (open) {
                     e.owner_fetch_selected(p);
                     e.owner_results(p, nullptr, which_prev, !burn);
@@ -1050,7 +1059,10 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
                 if (redraw_pending)
                     __syncthreads();
                 const int which_next = !sweep ? -1 : (which + 1 == n ? 0 : which + 1);
-                e.owner_publish(p, which_next);
+#if !APEMOST_HOIST_CAND
+                const double2 nx = e.owner_fetch_next_cand();
+#endif
+                e.owner_publish(p, nx, which_next);
                 e.tick++;
                 __syncthreads();
                 p ^= 1;

@@ -592,10 +592,12 @@ struct ObEngine {
         m.load(row, n_par, x_abs_max);
         OB_SEG(2); // the proposal in flight
     }
-    __device__ __forceinline__ void owner_publish(int parity, int which_next = -1) {
+    // candidates of the next tick: published by the barrier that opened this step; requested with the
+    // step's first batch of LDS reads (APEMOST_HOIST_CAND: config 2 2.036 -> 2.066e8 steps/s, config 4
+    // 2.29 -> 2.33e8, tools/gpu_exp_hoist.sh), not where the proposals need them
+    __device__ __forceinline__ double2 owner_fetch_next_cand() const { return s_cand(tick + 1)[lane]; }
+    __device__ __forceinline__ void owner_publish(int parity, double2 nx, int which_next = -1) {
         const int next = parity ^ 1;
-        // candidates of the next tick: published by the barrier that opened this step
-        const double2 nx = s_cand(tick + 1)[lane];
         next_y = nx.x;
         next_s = nx.y;
         // the two proposals of the next step: from the proposal in flight, from the current point
