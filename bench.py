@@ -271,12 +271,14 @@ def main():
     launch_ms = ev_ms.value / max(launches.value, 1)
     steps_per_launch = (a.steps * LPS * R * n_swap * n_local) / max(launches.value, 1)
     achieved_gbs = bytes_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9
-    # fp64 operations per data point as the kernels issue them, an FMA counted as two (DESIGN.md 5):
+    # fp64 operations per data point as the kernels issue them, an FMA counted as two (DESIGN.md 5, 16):
     # a sine with its argument is 28 (3 + reduction 7 + polynomial 18); simplesin adds 5 around it,
-    # sine3 2 per sine and 4 per point; the pulse models per mode 19 (one division by reciprocal),
-    # plus logarithm and final quotient ~50; pulse_vrot 61 instructions, 38 of them FMAs
+    # sine3 2 per sine and 4 per point; the pulse models since round 3 (spectrum over a common
+    # denominator, one reciprocal per two points, one logarithm per lane): two modes 10 additions /
+    # products and 5.5 FMAs per point, pulse_vrot 13.5 and 9 (more than three modes: a division by
+    # reciprocal per mode, 13 each, and 9 for the quotient)
     modes = max(1, (w.n_par - 2) // 2)
-    flops_per_point = {"simplesin": 33.0, "sine3": 3 * 30.0 + 4, "pulse": 19.0 * modes + 50, "pulse_vrot": 99.0}
+    flops_per_point = {"simplesin": 33.0, "sine3": 3 * 30.0 + 4, "pulse": 21.0 if modes <= 3 else 13.0 * modes + 9, "pulse_vrot": 31.5}
     flops_per_step = flops_per_point.get(w.name, 40.0) * w.n_data
     # What the PMC counters say cannot be read inside this process: `traffic` stays null in this line;
     # the HBM bytes and the VALU instruction count profiled with `rocprofv3 --pmc` on this same command
