@@ -559,7 +559,7 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
 #if !APEMOST_HOIST_CAND
                 const double2 nx = e.owner_fetch_next_cand();
 #endif
-                e.owner_publish(p, nx);
+                e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior>(p, nx);
                 e.tick++;
                 OB_STAMP_END;
                 __syncthreads();
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
 #if !APEMOST_HOIST_CAND
                 const double2 nx = e.owner_fetch_next_cand();
 #endif
-                e.owner_publish(p, nx, which_next);
+                e.template owner_publish<true>(p, nx, which_next);
                 e.tick++;
                 __syncthreads();
                 p ^= 1;

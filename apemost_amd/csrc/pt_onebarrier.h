@@ -447,6 +447,49 @@ struct ObEngine {
             row[grp] = from;
         return __ballot(active && qidx == 0 && (mask & grpmask) == 0);
     }
+    // attempts() for both prepared proposals of the next step at once -- from `from_a` (the proposal in
+    // flight) into row_a, from `from_r` (the current point) into row_r: the same arithmetic per variant,
+    // but ONE uniform branch for the circular / proposal-law path instead of one per variant, and the two
+    // variants' compare -> ballot -> predicated LDS write chains in one basic block, where the compiler
+    // interleaves them (two calls are two regions, one behind the other)
+    __device__ __forceinline__ void attempts2(double from_a, double from_r, double cy, double cs, double *row_a, double *row_r,
+                                              int which, u64 &failed_a, u64 &failed_r) const {
+        const double jump = stepw * cy * cs;
+        double prop_a = from_a + jump, prop_r = from_r + jump;
+        bool inside_a = !(prop_a > hi || prop_a < lo), inside_r = !(prop_r > hi || prop_r < lo);
+        if (circular != 0) { // uniform: a non-default proposal law, or some parameter is circular
+            if (kVariants && proposal_law(circular) == kProposalFlat) {
+                const double fj = flat_jump(stepw, cy);
+                prop_a = from_a + fj;
+                prop_r = from_r + fj;
+                inside_a = !(prop_a > hi || prop_a < lo);
+                inside_r = !(prop_r > hi || prop_r < lo);
+            }
+            const bool circ = (circular >> grp) & 1;
+            const bool wrap_a = !inside_a && circ, wrap_r = !inside_r && circ;
+            if (wrap_a)
+                prop_a = wrap_circular(prop_a, lo, hi);
+            if (wrap_r)
+                prop_r = wrap_circular(prop_r, lo, hi);
+            inside_a = inside_a || wrap_a;
+            inside_r = inside_r || wrap_r;
+        }
+        const bool active = cand() && (which < 0 || which == grp);
+        const bool usable = active && (cs == cs);
+        const bool ok_a = usable && inside_a, ok_r = usable && inside_r;
+        const u64 mask_a = __ballot(ok_a), mask_r = __ballot(ok_r);
+        if (ok_a && (mask_a & lowmask) == 0)
+            row_a[grp] = prop_a;
+        if (ok_r && (mask_r & lowmask) == 0)
+            row_r[grp] = prop_r;
+        if (which >= 0 && cand() && !active && qidx == 0) {
+            row_a[grp] = from_a;
+            row_r[grp] = from_r;
+        }
+        const bool leader = active && qidx == 0;
+        failed_a = __ballot(leader && (mask_a & grpmask) == 0);
+        failed_r = __ballot(leader && (mask_r & grpmask) == 0);
+    }
     // Engine::propose's rare path: none of the Q prepared attempts of a parameter worked -> the
     // whole wave tries 64 more at a time (attempt indices continue at Q, as in the serial loop of
     // src/markov_chain.c:235-240)
@@ -596,13 +639,22 @@ struct ObEngine {
     // step's first batch of LDS reads (APEMOST_HOIST_CAND: config 2 2.036 -> 2.066e8 steps/s, config 4
     // 2.29 -> 2.33e8, tools/gpu_exp_hoist.sh), not where the proposals need them
     __device__ __forceinline__ double2 owner_fetch_next_cand() const { return s_cand(tick + 1)[lane]; }
+    // MERGED: both prepared proposals through attempts2() (measured, tools/gpu_exp_hoist.sh with
+    // APEMOST_ATTEMPTS2: the calibration kernels 3-7 % faster and config 4's round kernel 2.345 -> 2.375e8
+    // steps/s with it, config 2's round kernel 2.07 -> 2.04e8: the round kernel of the models without a
+    // prior keeps the two calls)
+    template <bool MERGED>
     __device__ __forceinline__ void owner_publish(int parity, double2 nx, int which_next = -1) {
         const int next = parity ^ 1;
         next_y = nx.x;
         next_s = nx.y;
         // the two proposals of the next step: from the proposal in flight, from the current point
-        fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0), which_next);
-        fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
+        if constexpr (MERGED) {
+            attempts2(par_val, cur, next_y, next_s, s_prop(next, 0), s_prop(next, 1), which_next, fail_a, fail_r);
+        } else {
+            fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0), which_next);
+            fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
+        }
         OB_SEG(3); // next candidates, both prepared proposals
         // S_max of the step in flight
         double prior_new = 0;
