@@ -97,7 +97,10 @@ def test_pulse_loglike_over_a_wide_range_of_units(name):
     The same spectrum in other units -- frequencies in units 1e6 times smaller or larger (the lifetime
     scaled with them), heights and data 1e60 times smaller or larger -- against the oracle, which adds a
     gsl_sf_log per point: 1e-12 as everywhere, ragged length, one and four waves per chain."""
-    w = small_workloads()[name]
+    # (1100 points: four passes of the one-wave kernel's long loop -- where pulse_vrot shares a reciprocal
+    # among FOUR points and takes the sum again when their products leave the range, as they do at the
+    # largest heights here -- and a ragged rest)
+    w = wl.pulse(n_data=1100, n_chain=2) if name == "pulse" else wl.pulse_vrot(n_data=1100, n_chain=2)
     rs = np.random.RandomState(5)
     base = w.pmin + (w.pmax - w.pmin) * rs.uniform(0.2, 0.8, size=(5, w.n_par))
     beta = rs.uniform(0.05, 1.0, len(base))
@@ -105,7 +108,7 @@ def test_pulse_loglike_over_a_wide_range_of_units(name):
     freqs = [2, 4] if name == "pulse" else [2, 3, 5]                  # (pulse_vrot: vrot, fa, fb)
     for sf in (1e-6, 1.0, 1e6):
         for sh in (1e-60, 1.0, 1e60):
-            data = w.data[:301].copy()
+            data = w.data.copy()
             data[:, 0] *= sf
             data[:, 1] *= sh
             params = base.copy()
