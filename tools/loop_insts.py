@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
-"""Innermost loops of a kernel in a disassembly (llvm-objdump -d --no-show-raw-insn of the gfx950 code
-object): for every backward branch, the number of VALU / SALU / LDS / VMEM instructions between the
-target and the branch, and how many v_rcp_f64 (one per data point in the pulse models; per sine: v_rndne).
+"""Loops of a kernel in the gfx950 code object of a built library or object file: for every backward
+branch, the number of VALU / SALU / LDS / VMEM instructions and waits between its target and the
+branch, and how many v_rcp_f64 (one per data point or pair of points in the pulse models).  What the
+instruction counts per data point in DESIGN.md 16 were read from.  No GPU needed.
 
     python tools/loop_insts.py <model_N.o | lib.so> '<substring of the demangled kernel name>'
 """
-import os, re, subprocess, sys, tempfile
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
 LLVM = "/opt/rocm/lib/llvm/bin"
+
 
 def disassemble(path):
     tmp = tempfile.mkdtemp()
@@ -14,66 +21,66 @@ def disassemble(path):
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, fat])
     subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    txt = subprocess.check_output([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co]).decode()
-    return subprocess.run(["c++filt"], input=txt.encode(), stdout=subprocess.PIPE).stdout.decode()
+    txt = subprocess.check_output([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co])
+    return subprocess.run(["c++filt"], input=txt, stdout=subprocess.PIPE).stdout.decode()
 
-def main():
-    path, want = sys.argv[1], sys.argv[2]
-    txt = disassemble(path)
+
+def kernels(txt):
     cur, body = None, {}
     for line in txt.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
         if m:
             cur = m.group(1)
             body[cur] = []
-            continue
-        if cur and line.strip():
+        elif cur and line.strip():
             body[cur].append(line)
-    for name, lines in body.items():
-        if want not in name or name.startswith("L") or not lines:
+    return body
+
+
+def classify(op, c):
+    if op.startswith("v_"):
+        c["valu"] += 1
+    elif op.startswith("ds_"):
+        c["lds"] += 1
+    elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        c["vmem"] += 1
+    elif op.startswith("s_waitcnt"):
+        c["wait"] += 1
+    elif op.startswith("s_"):
+        c["salu"] += 1
+    if op.startswith("v_rcp_f64"):
+        c["rcp"] += 1
+
+
+def main():
+    path, want = sys.argv[1], sys.argv[2]
+    for name, lines in kernels(disassemble(path)).items():
+        if want not in name:
             continue
         insts = []
-        for l in lines:
-            m = re.match(r"^\s*(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", l)
+        for line in lines:
+            m = re.match(r"^\s*(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
             if m:
                 insts.append((int(m.group(3), 16), m.group(1), m.group(2)))
-        addr_index = {a: i for i, (a, _, _) in enumerate(insts)}
+        index = {a: i for i, (a, _, _) in enumerate(insts)}
         print(name, len(insts), "instructions")
-        for i, (a, op, args) in enumerate(insts):
-            if op.startswith("s_cbranch") or op == "s_branch":
-                m = re.search(r"<[^>]*\+0x([0-9a-f]+)>", args)
-                lab = None
-                # objdump prints the target as a symbol+offset or an absolute address
-                m2 = re.search(r"(\d+)\s*$", args)
-                tgt = None
-                for t in re.findall(r"0x([0-9a-f]+)", l if False else args):
-                    pass
-                # compute from the encoded simm16 when shown as a plain number
-                if m2 and not m:
-                    simm = int(m2.group(1))
-                    if simm >= 32768:
-                        simm -= 65536
-                    tgt = a + 4 + 4 * simm
-                if tgt is None or tgt >= a or tgt not in addr_index:
-                    continue
-                j = addr_index[tgt]
-                seg = insts[j:i + 1]
-                inner = not any((o.startswith("s_cbranch") or o == "s_branch") and k < len(seg) - 1 and False for k, (_, o, _) in enumerate(seg))
-                c = {"valu": 0, "salu": 0, "lds": 0, "vmem": 0, "rcp": 0, "wait": 0}
-                for _, o, _ in seg:
-                    if o.startswith("v_"):
-                        c["valu"] += 1
-                    elif o.startswith("ds_"):
-                        c["lds"] += 1
-                    elif o.startswith(("global_", "buffer_", "flat_", "scratch_")):
-                        c["vmem"] += 1
-                    elif o.startswith("s_waitcnt"):
-                        c["wait"] += 1
-                    elif o.startswith("s_"):
-                        c["salu"] += 1
-                    if o == "v_rcp_f64_e32" or o == "v_rcp_f64_e64":
-                        c["rcp"] += 1
-                if c["valu"] >= 20:
-                    print("  loop %06x..%06x: %s" % (tgt, a, c))
+        for i, (addr, op, args) in enumerate(insts):
+            if not (op.startswith("s_cbranch") or op == "s_branch"):
+                continue
+            m = re.match(r"(\d+)", args)            # the branch offset in dwords, as objdump prints it
+            if not m:
+                continue
+            simm = int(m.group(1))
+            if simm >= 32768:
+                simm -= 65536
+            target = addr + 4 + 4 * simm
+            if target >= addr or target not in index:
+                continue
+            c = {"valu": 0, "salu": 0, "lds": 0, "vmem": 0, "rcp": 0, "wait": 0}
+            for _, o, _ in insts[index[target]:i + 1]:
+                classify(o, c)
+            if c["valu"] >= 20:
+                print("  loop %06x..%06x: %s" % (target, addr, c))
+
 
 main()
