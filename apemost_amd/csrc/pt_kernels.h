@@ -475,6 +475,8 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
         OB_STAMP_FLUSH;
     } else if (e.is_producer()) {
         e.setup_lanes(a.sh, c);
+        if constexpr (decltype(e)::kSplit)
+            e.setup_helper(a.d, a.sh, c);
         e.producer_prologue();
         __syncthreads();
         int p = 0;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
                 OB_STAMP_BEGIN;
                 if (e.redraw_pending(p))
                     __syncthreads();
-                e.producer_step();
+                e.producer_step(p);
                 OB_STAMP_END;
                 __syncthreads();
                 p ^= 1;
@@ -559,10 +561,21 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
 #if !APEMOST_HOIST_CAND
                 const double2 nx = e.owner_fetch_next_cand();
 #endif
+#ifdef APEMOST_EXP_OWNER_SLACK
+                // TIMING ONLY (results are garbage; tools/experiments/r04_slack.sh): the owner arrives at the
+                // step's barrier with half of its work done and publishes behind it -- what a step costs when
+                // nobody waits for the owner's whole program (the two-step look-ahead of DESIGN.md 9 would
+                // give it that slack).  The redraw flag is never set in this build.
+                __syncthreads();
+                e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior>(p, nx);
+                e.tick++;
+                OB_STAMP_END;
+#else
                 e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior>(p, nx);
                 e.tick++;
                 OB_STAMP_END;
                 __syncthreads();
+#endif
 #ifdef APEMOST_STAMPS
                 ob_total += __builtin_amdgcn_s_memtime() - ob_t0;
 #endif
@@ -815,7 +828,15 @@ void pt_calibrate_kernel(const CalibArgs a) {
     for (;;) {
         // (every wave reads the same words: the branches below are uniform)
         const int stage = __builtin_amdgcn_readfirstlane(r.stage);
-        if (stage == CAL_DONE || r.evals >= stop_at)
+        const u64 evals_now = r.evals, iter_now = r.iter;
+        // Every wave has read the record before thread 0 writes it again: three transitions below (INIT ->
+        // BURN1, BURN1 -> BURN2, BURN2 -> SWEEP / DONE) take no step and so have no barrier of their own
+        // between this read and the write at the loop's end -- a wave that left the previous barrier late
+        // would read the NEXT stage and fall one barrier out of phase with wave 0.  One barrier
+        // per block of >= 200 steps.
+        if (WAVES > 1)
+            __syncthreads();
+        if (stage == CAL_DONE || evals_now >= stop_at)
             break;
         int next = stage; // (what wave 0 arrives at is what counts: thread 0 writes it)
         if (stage == CAL_INIT) {
@@ -828,7 +849,7 @@ void pt_calibrate_kernel(const CalibArgs a) {
                 r.iter = 0;
         } else if (stage == CAL_BURN1 || stage == CAL_BURN2) {
             const u64 limit = stage == CAL_BURN1 ? cfg.burn_in_iterations / 2 : cfg.burn_in_iterations;
-            if (r.iter < limit) {
+            if (iter_now < limit) {
                 for (int sub = 0; sub < 200; sub++)
                     e.step(-1);
                 if (w0)
@@ -967,6 +988,8 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
         }
     } else if (e.is_producer()) {
         e.setup_lanes(a.sh, c);
+        if constexpr (decltype(e)::kSplit)
+            e.setup_helper(a.d, a.sh, c);
         e.producer_prologue();
         __syncthreads();
         for (;;) {
@@ -978,7 +1001,7 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
             for (int s = 0; s < n_steps; s++) {
                 if (e.redraw_pending(p))
                     __syncthreads();
-                e.producer_step();
+                e.producer_step(p);
                 __syncthreads();
                 p ^= 1;
             }

@@ -43,7 +43,9 @@ constexpr int kObPart = 0;                        // [2][16] wave partials of th
 constexpr int kObThr = 32;                        // [2]     S_max of the step the partials belong to
 constexpr int kObFlag = 34;                       // [2]     != 0: a prepared proposal needs the redraw path
 constexpr int kObCtl = 36;                        // 4 control words (word 2 of the int view: Engine's fail flag slot)
-constexpr int kObProp = 40;                       // [2][2][64] proposals: [parity][0 = after accept, 1 = after reject][parameter]
+constexpr int kObThx = 40;                        // [2]     models with a prior: the helper's half of S_max (kObThr then holds the owner's half)
+constexpr int kObPri = 42;                        // [2]     ... and the prior of the proposal that half belongs to
+constexpr int kObProp = 44;                       // [2][2][64] proposals: [parity][0 = after accept, 1 = after reject][parameter]
 constexpr int kObCand = kObProp + 2 * 2 * kWave;  // [8][64] double2 candidate ring
 constexpr int kObLogTab = kObCand + 8 * 2 * kWave;  // the logarithm's table (pulse models)
 constexpr int kObFixedDoubles = kObLogTab + kLogTabLdsDoubles;
@@ -52,8 +54,15 @@ constexpr int kObFixedDoubles = kObLogTab + kLogTabLdsDoubles;
 template <int MODEL>
 struct ObThreshold;
 
+// kSplit (the models with a prior): S_max = X - Y in two halves that different wavefronts compute side by
+// side -- X from the proposal alone (its prior and additive parameter: the helper, a candidate producer), Y
+// from the chain (T: the owner) -- and every wave subtracts for itself behind the barrier.  The prior's
+// logarithm was 616 of the 2194 ticks the owner was busy per step at config 4, with everybody waiting for
+// it (profiles/r03_ob_owner_segments.txt); it depends on nothing the owner knows that the published rows
+// and the decision every wave makes anyway do not say (round 4).
 template <>
 struct ObThreshold<APEMOST_MODEL_SIMPLESIN> {
+    static constexpr bool kSplit = false;
     double denom_over_beta; // (-2 sigma^2) / beta < 0
     __device__ __forceinline__ void init(const ModelConsts &c, double beta) {
         denom_over_beta = (-2 * c.sigma * c.sigma) / beta;
@@ -70,13 +79,13 @@ struct ObThreshold<APEMOST_MODEL_SINE3> : ObThreshold<APEMOST_MODEL_SIMPLESIN> {
 
 template <>
 struct ObThreshold<APEMOST_MODEL_PULSE> {
+    static constexpr bool kSplit = true;
     double inv_beta;
     __device__ __forceinline__ void init(const ModelConsts &, double beta) { inv_beta = 1.0 / beta; }
-    // prob_new = prior + -beta (p1 + S) > T  <=>  S < (prior - T) / beta - p1
-    template <class M>
-    __device__ __forceinline__ double s_max(double T, const M &, double prior_new, double p1) const {
-        return (prior_new - T) * inv_beta - p1;
-    }
+    // prob_new = prior + -beta (p1 + S) > T  <=>  S < (prior - T) / beta - p1 = (prior / beta - p1) - T / beta
+    __device__ __forceinline__ double x_part(double prior_new, double p1) const { return prior_new * inv_beta - p1; }
+    __device__ __forceinline__ double y_part(double T) const { return T * inv_beta; }
+    static __device__ __forceinline__ double limit(double x, double y) { return x - y; }
 };
 template <>
 struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> {};
@@ -151,6 +160,9 @@ struct ObEngine {
 
     __device__ __forceinline__ double *s_part(int parity) const { return lds + kObPart + parity * 16; }
     __device__ __forceinline__ double *s_thr(int parity) const { return lds + kObThr + parity; }
+    __device__ __forceinline__ double *s_thx(int parity) const { return lds + kObThx + parity; }
+    __device__ __forceinline__ double *s_pri(int parity) const { return lds + kObPri + parity; }
+    static constexpr bool kSplit = ObThreshold<kBase>::kSplit;
     __device__ __forceinline__ int *s_flag(int parity) const { return (int *)(lds + kObFlag + parity); }
     // uniform by construction (every lane reads the same word): say so, the branch on it guards a barrier
     __device__ __forceinline__ bool redraw_pending(int parity) const {
@@ -307,8 +319,35 @@ struct ObEngine {
         if (j == 0)
             pipe_log = cand_log(pipe);
     }
-    __device__ __forceinline__ void producer_step() {
+    // The helper's duty (kSplit), carried by whichever producer is in the phase with the shortest chain of
+    // its own (the Philox blocks: exactly one of the three at every step): decide the step that just ended
+    // like every other wave, take the prior of the proposal now in flight -- the row that decision selects
+    // -- and publish the proposal's half of S_max with it.  `parity` as in lik_step.
+    __device__ __forceinline__ void setup_helper(const DevArrays &d, const ChainShape &sh, int c) {
+        consts = sh.consts;
+        beta_all = d.beta()[c + 1];
+        thr_fn.init(consts, beta_all);
+        m.init_scalar();
+        if constexpr (Model<kBase>::kUsesLogTable)
+            m.set_lean(false);
+        m.set_consts(consts);
+    }
+    __device__ __forceinline__ void helper_step(int parity) {
+        const double sum = tree(parity);
+        const double limit = ObThreshold<kBase>::limit(*s_thx(parity), *s_thr(parity));
+        const double *row = s_prop(parity, sum < limit ? 0 : 1);
+        m.load_offset(row, n_par);
+        const double pr = m.prior_only(consts);
+        const double x = thr_fn.x_part(pr, m.offset());
+        if (lane == 0) {
+            *s_thx(parity ^ 1) = x;
+            *s_pri(parity ^ 1) = pr;
+        }
+    }
+    __device__ __forceinline__ void producer_step(int parity) {
         if (pipe_phase == 0) {
+            if constexpr (kSplit)
+                helper_step(parity);
             pipe = cand_begin(pipe_tick);
             pipe_phase = 1;
         } else if (pipe_phase == 1) {
@@ -383,8 +422,16 @@ struct ObEngine {
             else
                 acc += m.term(xs[i], ys[i]);
         }
-        if constexpr (Model<kBase>::kLogProduct)
+        if constexpr (Model<kBase>::kLogProduct) {
             acc += lp.template finish<false>(m.tab);
+            // rare: a pair product next to the subnormals or a sum that is not finite -- the wave takes its
+            // share again in the reference's operation order (LogProdT, Model::term_ref)
+            if (__ballot(lp.bad(acc)) != 0) {
+                acc = 0;
+                for (int k = tid; k < n_data; k += kLikThreads)
+                    acc += m.term_ref(xs[k], ys[k]);
+            }
+        }
         return wave_reduce_sum_lane63(acc); // valid in lane 63
     }
 
@@ -399,7 +446,9 @@ struct ObEngine {
 #pragma unroll
         for (int w = 0; w < LW; w++)
             part[w] = sp[w];
-        const double limit = *s_thr(parity);
+        double limit = *s_thr(parity);
+        if constexpr (kSplit)
+            limit = ObThreshold<kBase>::limit(*s_thx(parity), limit); // (one subtraction beside the partial sums' tree)
         const int pending = *s_flag(parity);
         m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
         if (__builtin_amdgcn_readfirstlane(pending) != 0) {
@@ -541,7 +590,9 @@ struct ObEngine {
         if (lane < n_par)
             s_prop(0, 0)[lane] = row[lane];
         if (lane == 0) {
-            *s_thr(0) = __builtin_inf();
+            *s_thr(0) = kSplit ? 0.0 : __builtin_inf();
+            if constexpr (kSplit)
+                *s_thx(0) = __builtin_inf(); // (X - Y = +inf: "take either")
             *s_flag(0) = 0;
         }
         if (lane < LW)
@@ -583,6 +634,12 @@ struct ObEngine {
     // (src/markov_chain.c:48-58), not after every step
     __device__ __forceinline__ void owner_results(int parity, double *sample, int which = -1, bool check_best = true) {
         const double sum = tree(parity);
+        if constexpr (kSplit) {
+            // the helper's half of the threshold and the prior it took for it, published by the barrier
+            // that closed the step; `thr` holds the owner's own half since owner_publish
+            thr = ObThreshold<kBase>::limit(*s_thx(parity), thr);
+            prior_inflight = *s_pri(parity);
+        }
         accepted = sum < thr;
         OB_SEG(0); // LDS batch, partial sums, decision
         // (the proposal's prior was computed for its threshold, a step ago: not again)
@@ -623,7 +680,11 @@ struct ObEngine {
     // two prepared proposals of the step after it into the other parity
     __device__ __forceinline__ void owner_choose(int parity, bool first) {
         double *row = s_prop(parity, (first || accepted) ? 0 : 1);
+#ifdef APEMOST_EXP_OWNER_SLACK
+        const u64 failed = 0;
+#else
         const u64 failed = first ? 0 : (accepted ? fail_a : fail_r);
+#endif
         // the value my parameter takes in the chosen proposal was read back when the proposals were
         // prepared (sel_a / sel_r): no trip to LDS between the accept decision and the next proposals
         par_val = (first || accepted) ? sel_a : sel_r;
@@ -632,7 +693,10 @@ struct ObEngine {
             __builtin_amdgcn_wave_barrier();
             par_val = cand() ? row[grp] : 0.0;
         }
-        m.load(row, n_par, x_abs_max);
+        if constexpr (kSplit)
+            m.load_offset(row, n_par); // (finish_known_prior reads the additive parameter, nothing else)
+        else
+            m.load(row, n_par, x_abs_max);
         OB_SEG(2); // the proposal in flight
     }
     // candidates of the next tick: published by the barrier that opened this step; requested with the
@@ -656,17 +720,20 @@ struct ObEngine {
             fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
         }
         OB_SEG(3); // next candidates, both prepared proposals
-        // S_max of the step in flight
-        double prior_new = 0;
-        if (Model<kBase>::kHasPrior)
-            prior_new = m.prior_only(consts);
-        prior_inflight = prior_new;
-        OB_SEG(4); // the prior of the proposal in flight
+        // S_max of the step in flight (kSplit: the chain's half of it; the helper adds the proposal's)
+        OB_SEG(4); // (the prior of the proposal in flight: the helper's since round 4)
         const double lu = read_lane(cand_y, 63);
-        thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());
+        if constexpr (kSplit)
+            thr = thr_fn.y_part(prob + lu);
+        else
+            thr = thr_fn.s_max(prob + lu, m, 0.0, 0.0);
         if (lane == 0) {
             *s_thr(next) = thr;
+#ifdef APEMOST_EXP_OWNER_SLACK
+            *s_flag(next) = 0;
+#else
             *s_flag(next) = (fail_a | fail_r) != 0 ? 1 : 0;
+#endif
         }
         OB_SEG(5); // threshold, flags
     }

@@ -5,7 +5,9 @@ Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distr
 rank per GPU over RCCL).  One bench "step" = one pass of the hot path over one batch of synthetic
 work: LAUNCHES_PER_STEP launches of ROUNDS_PER_STEP rounds of {n_swap Metropolis steps per chain + one
 swap attempt} (run_sampler's loop body, src/parallel_tempering.c:392-409), sample rows written to HBM
-(20 steps are about a second of GPU time).
+(20 steps are >= 5 s of GPU time).
+With --gpus N > 1 and no torch.distributed environment, bench.py starts the N ranks itself (fresh child
+processes, one per GPU; the parent never touches a GPU) and rank 0 prints the line.
 Workload at every N: BASELINE config 2 per GPU -- simplesin, 128 chains x 1024 data points per
 GPU (weak scaling: the ladder has 128*N chains, block-partitioned over the ranks).
 `--config 3|4|5` selects the other GPU configs of BASELINE.json (per-GPU share of the ladder,
@@ -32,14 +34,15 @@ FP64_VALU_PEAK_TF = 78.6  # fp64 vector peak
 # rounds_per_step: rounds of one bench step = of one launch where the ladder is resident (the C host
 # launches up to apemost_hip_max_rounds_per_launch rounds at a time, bounded by its sample buffers):
 # chosen so that a launch is ~1 ms of work and its fixed cost (launch, staging, pipeline start) is small
-# launches_per_step: a bench step is that many such batches back to back, so that 20 steps are about a
-# second of GPU time (the driver's utilisation sampling and its own clock then see the kernel; the
-# timed region of round 2 was 25 ms)
+# launches_per_step: a bench step is that many such batches back to back, so that the driver's 20 steps are
+# >= 5 s of GPU time at every config (its utilisation sampler and its own clock then see the kernel: the
+# timed region was 25 ms in round 2 and ~1 s in round 3, where the sampler's three looks all read 0 %);
+# `value` does not depend on it
 CONFIGS = {
-    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000, rounds_per_step=128, launches_per_step=40),
-    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000, rounds_per_step=32, launches_per_step=64),
-    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000, rounds_per_step=256, launches_per_step=120),  # 2048 / 8 GPUs
-    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600, rounds_per_step=32, launches_per_step=6),  # 16384 / 8 GPUs
+    2: dict(workload="simplesin", chains_per_gpu=128, n_data=1024, n_swap=0, burn_in=10000, rounds_per_step=128, launches_per_step=260),
+    3: dict(workload="sine3", chains_per_gpu=1024, n_data=8192, n_swap=0, burn_in=2000, rounds_per_step=32, launches_per_step=480),
+    4: dict(workload="pulse", chains_per_gpu=256, n_data=1024, n_swap=1, burn_in=2000, rounds_per_step=256, launches_per_step=1100),  # 2048 / 8 GPUs
+    5: dict(workload="pulse_vrot", chains_per_gpu=2048, n_data=65536, n_swap=1, burn_in=600, rounds_per_step=32, launches_per_step=70),  # 16384 / 8 GPUs
 }
 
 
@@ -81,6 +84,39 @@ def parse():
     return a
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: N fresh child processes of this same command
+    line, one rank per GPU, rendezvous on 127.0.0.1 at a free port.  This process never initialises a GPU
+    (no exec after a GPU call, no fork of a process that holds one); rank 0's stdout is ours, so its ONE
+    JSON line is the line.  Returns the exit code: the first failing rank's, after the others are ended."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:        # one rank is gone: the others would wait for it until a timeout
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def host_cores():
     """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota
     (the GPU box exposes 256 hardware threads but grants a share of them)."""
@@ -116,6 +152,30 @@ def cpu_baseline(w, st_template, n_swap, seconds):
                       % (rounds, n_swap, st_template.n_chain, dt)}
 
 
+def kernel_sources_sha1():
+    """sha1 over the kernel sources (csrc/*.h, *.hip): tools/summarize_profile.py stores it with the counters it
+    registers in profiles/pmc_traffic.json, so that a line can say whether they belong to this build"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "apemost_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def expected_kernel(model, waves, lds, one_barrier, flags):
+    """the instantiation the sampler's run phase launches, as rocprofv3 names it (pt_kernels.h launch_one;
+    the proposal-law / RANDOMSWAP variants are MODEL + 8; workgroups of >= 4 waves of the two-phase kernel
+    carry the candidate producers)"""
+    variant = 8 if flags & (8 | 16 | 32) else 0
+    b = "true" if lds else "false"
+    if one_barrier:
+        return "apemost::pt_round_ob_kernel<%d, %d, %s>" % (model + variant, waves, b)
+    return "apemost::pt_round_kernel<%d, %d, %s, %s>" % (model + variant, waves, b, "true" if waves >= 4 else "false")
+
+
 def calibration_block(wall_s, status, iters, ccfg, n_par):
     """What the device calibration before the timed region did (markov_chain_calibrate for every chain
     of the shard: burn_in + markov_chain_calibrate_orig, src/markov_chain_calibrate.c:1039-1180).
@@ -145,11 +205,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (a.gpus, a.gpus))
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(spawn_ranks(a.gpus))   # (before anything in this process has touched a GPU)
         a.gpus = world
 
+    if os.environ.get("APEMOST_BENCH_TEST_FAIL_RANK") == str(rank):   # test hook (tests/test_gpu_bench_ranks.py)
+        raise SystemExit(7)
     import torch
     import torch.distributed as dist
     from apemost_amd import capi, workloads as wl
@@ -284,14 +345,22 @@ def main():
     # the HBM bytes and the VALU instruction count profiled with `rocprofv3 --pmc` on this same command
     # (profiles/README.md, profiles/pmc_traffic.json) are quoted when the workload is the one they
     # were measured on.
-    traffic_profiled = valu_insts = profile_src = None
+    # Counters are only quoted for the kernel they were measured on: same workload key, same waves per chain
+    # AND the same kernel instantiation as this sampler launches; `profile_kernel_sources_changed` says whether
+    # the kernel sources have changed since that profile was taken (then the instruction count is that of an
+    # older build of the same kernel: re-profile with tools/profile_config.sh).
+    one_barrier = waves in (4, 8) and not (a.flags & 4)
+    kernel_name = expected_kernel(w.model, waves, lds, one_barrier, a.flags)
+    traffic_profiled = valu_insts = profile_src = profile_stale = None
     key = "%s/%d/%d/%d/%d/%s" % (w.name, n_local, w.n_data, n_swap, R, "nosamples" if a.no_samples else "samples")
     try:
         for pmc in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
-            if pmc.get("workload_key") == key and pmc.get("waves_per_chain", waves) == waves:
+            if (pmc.get("workload_key") == key and pmc.get("waves_per_chain") == waves
+                    and pmc.get("kernel", "").replace("void ", "").split("(")[0] == kernel_name):
                 traffic_profiled = pmc.get("hbm_bytes_per_launch")
                 valu_insts = pmc.get("valu_wave_insts_per_launch", valu_insts)
                 profile_src = pmc.get("tag", profile_src)
+                profile_stale = pmc.get("kernel_sources_sha1") != kernel_sources_sha1()
     except (OSError, ValueError, KeyError, TypeError):
         pass
     # The roofline that binds.  The data vector is resident in LDS or L2 by design (HBM traffic is
@@ -302,14 +371,13 @@ def main():
     props = torch.cuda.get_device_properties(local_rank)
     clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
     cus = props.multi_processor_count
-    one_barrier = waves in (4, 8) and not (a.flags & 4)
     waves_per_wg = waves + 4 if one_barrier else waves
     cus_occupied = min(cus, n_local)
     simds_occupied = min(4 * cus, n_local * min(4, waves_per_wg))
     launch_s = launch_ms * 1e-3
     fp64_frac = flops_per_step * steps_per_launch / launch_s / 1e12 / FP64_VALU_PEAK_TF
     roof = {"traffic": None, "traffic_profiled": traffic_profiled,
-            "kernel": "pt_round_ob_kernel" if one_barrier else "pt_round_kernel", "launch_us": launch_ms * 1e3,
+            "kernel": kernel_name, "profile_kernel_sources_changed": profile_stale, "launch_us": launch_ms * 1e3,
             "cus_occupied": cus_occupied, "cus": cus, "simds_occupied": simds_occupied, "clock_mhz_peak": clock_hz / 1e6,
             # SURVEY 8(d)'s nominal figure: every step "streams" the data vector once (it does, from LDS / L2)
             "hbm_nominal_achieved": achieved_gbs, "hbm_nominal_peak": HBM_PEAK_GBS, "hbm_nominal_unit": "GB/s",

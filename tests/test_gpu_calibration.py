@@ -235,6 +235,27 @@ def test_calibration_cut_at_every_block_matches_oracle(name, waves, monkeypatch)
     s.close()
 
 
+@pytest.mark.parametrize("name,waves", [("simplesin", 2), ("simplesin", 4), ("pulse", 4), ("sine3", 8)])
+def test_two_phase_calibration_of_several_waves_cut_at_every_block_matches_oracle(name, waves, monkeypatch):
+    """pt_calibrate_kernel (the two-phase step) with more than one wave per chain, a launch per block:
+    every launch goes through the transitions that take no step (INIT -> BURN1, BURN1 -> BURN2, BURN2 ->
+    SWEEP), where all waves read the LDS record that thread 0 rewrites; they read it behind a barrier
+    of its own since round 4.  Waves 4 and 8 reach this kernel through
+    APEMOST_HIP_FLAG_TWO_BARRIER_STEP (PRODUCER variants)."""
+    monkeypatch.setenv("APEMOST_CALIB_SEGMENT_EVALS", "1")
+    w = small_workloads()[name]
+    n_chain = 3
+    dcfg, ocfg = _cfgs()
+    st, lad, rng, res = _oracle_calibration(w, n_chain, 19, ocfg)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=19, waves_per_chain=waves,
+                   flags=capi.FLAG_TWO_BARRIER_STEP)
+    s.set_state(st)
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    assert [(int(a), int(b)) for a, b in zip(status, iters)] == res
+    assert_match(s.get_state(), lad, rng, what="segmented two-phase calibrate %s waves=%d" % (name, waves))
+    s.close()
+
+
 def test_tail_of_a_calibration_gets_more_waves_per_chain_and_still_matches_oracle(monkeypatch):
     """The survivors of a calibration are launched again with the workgroup shape the engine would
     choose for a ladder of that many chains.  800 chains start with one wave each; the chains that

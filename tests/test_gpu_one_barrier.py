@@ -131,3 +131,74 @@ def test_one_barrier_config2_bench_shape_matches_oracle():
     assert_match(dev, lad, rng, what="config 2")
     np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
     assert dev.swapcount.sum() > 5
+
+
+@pytest.mark.parametrize("name", ["simplesin", "pulse"])
+def test_injected_ties_of_the_accept_comparison(name, capsys):
+    """check_accept (src/markov_chain.c:282-311) accepts iff prob_new == prob or prob_new > prob or
+    ln U < prob_new - prob; the one-barrier kernel decides the same question as ONE comparison on the raw
+    data sum, S < S_max(prob, ln U, prior) (pt_onebarrier.h ObThreshold).  Here the tie is injected: every
+    chain's `prob` is set to prob_new - ln U of its coming step (the kernel's own prob_new of that proposal,
+    taken from a first run in which everything is accepted; ln U of the tick from the oracle's stream) moved
+    by k = -12..12 units u, one step is run through apemost_hip_launch_round, and the decisions are compared
+    with the reference's rule evaluated on the same numbers.  u = one ulp of the largest number the
+    log-posterior is put together from -- max(|prob_new|, |prior|, |beta (p1 + S)|, |ln U|) 2^-52: that, not
+    the ulp of a `prob` that may be a small difference of large terms, is the rounding the reference's own
+    prob_new carries.
+      * the two-phase kernel uses the reference's comparison itself: identical for every k;
+      * the one-barrier kernel: identical outside a window of +-kWindow u around the tie (S_max is three
+        roundings away from the reference's difference), monotone in k -- never an accept above a reject --,
+        and inside the window it is the threshold form that decides."""
+    import torch
+    kWindow, kRange = 4, 12
+    w = small_workloads()[name]
+    n_chain, seed = 8, 61
+    st, _, _ = make_pair(w, n_chain, seed=seed)
+    st.prob[:] = -1e10                           # quirk Q2: the first proposal is accepted whatever it is
+
+    def one_step(state, flags):
+        s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=seed, waves_per_chain=4, flags=flags)
+        s.set_state(state)
+        d = torch.zeros((1, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
+        s.launch_round(1, False, d.data_ptr())
+        s.synchronize()
+        out = s.get_state(), d.cpu().numpy()[0]
+        s.close()
+        return out
+
+    first, rows = one_step(st, 0)
+    assert np.all(first.accept == 1)
+    prob_new = rows[:, w.n_par].copy()           # the kernel's own log-posterior of each chain's proposal
+    prior = prob_new - rows[:, w.n_par + 1]
+    ln_u = np.array([orc.accept_log_uniform(seed, c, w.n_par, 0) for c in range(n_chain)])
+    assert np.all(ln_u < 0)
+    tie = prob_new - ln_u                        # prob_new - tie ~ ln U
+    unit = 2.0 ** -52 * np.maximum.reduce([np.abs(prob_new), np.abs(prior), np.abs(prior - prob_new), np.abs(ln_u), np.abs(tie)])
+    ks = list(range(-kRange, kRange + 1))
+    table = {}
+    for k in ks:
+        inj = st.copy()
+        p = tie + k * unit
+        inj.prob[:] = p
+        ref = (prob_new == p) | (prob_new > p) | (ln_u < prob_new - p)
+        ob, rows_ob = one_step(inj, 0)
+        tp, rows_tp = one_step(inj, capi.FLAG_TWO_BARRIER_STEP)
+        assert np.array_equal(rows_ob[:, :w.n_par][ob.accept == 1], rows[:, :w.n_par][ob.accept == 1])
+        assert np.array_equal(tp.accept == 1, ref), (k, "two-phase kernel")
+        table[k] = (ref, ob.accept == 1)
+    flips = []
+    for c in range(n_chain):
+        ref_c = np.array([table[k][0][c] for k in ks])
+        ob_c = np.array([table[k][1][c] for k in ks])
+        flips.append(int(ob_c.sum()) - int(ref_c.sum()))   # units by which the threshold form's tie sits above the reference's
+    with capsys.disabled():
+        print("\n[%s] units u by which the one-barrier tie sits above the reference's, per chain: %s (u / ulp(prob): %s)"
+              % (name, flips, np.round(unit / np.spacing(np.abs(tie)), 1).tolist()))
+    for c in range(n_chain):
+        ref_c = np.array([table[k][0][c] for k in ks])
+        ob_c = np.array([table[k][1][c] for k in ks])
+        # a larger `prob` is harder to beat: accepts (small k) first, then rejects
+        assert np.all(np.diff(ob_c.astype(int)) <= 0) and np.all(np.diff(ref_c.astype(int)) <= 0), c
+        assert ob_c[0] and not ob_c[-1], c
+        differ = np.array(ks)[ref_c != ob_c]
+        assert np.all(np.abs(differ) <= kWindow), (c, differ)

@@ -89,14 +89,38 @@ def test_loglike_matches_oracle(name, waves):
     s.close()
 
 
+@pytest.mark.parametrize("name,n_data", [("sine3", 8192), ("pulse", 1024), ("pulse_vrot", 65536)])
+@pytest.mark.parametrize("waves", [1, 4])
+def test_loglike_matches_oracle_at_full_size(name, n_data, waves):
+    """test_loglike_matches_oracle on the data vectors of BASELINE configs 3, 4 and 5 (8192 / 1024 / 65 536
+    points): the stated 1e-12 where rounding has the most terms to grow over -- ln of a running product, one
+    reciprocal per two or four points, FMAs (VERDICT r3 weak #2)."""
+    w = wl.by_name(name, n_data=n_data, n_chain=2)
+    rs = np.random.RandomState(31)
+    n = 37
+    params = w.pmin + (w.pmax - w.pmin) * rs.uniform(0.05, 0.95, size=(n, w.n_par))
+    beta = rs.uniform(0.01, 1.0, n)
+    s = HipSampler(w.model, w.n_par, 2, w.data, waves_per_chain=waves)
+    prob, prior = s.loglike(params, beta)
+    ref = [orc.loglike(w.model, params[i], w.data, beta=beta[i]) for i in range(n)]
+    np.testing.assert_allclose(prob, [r[0] for r in ref], rtol=1e-12)
+    np.testing.assert_allclose(prior, [r[1] for r in ref], rtol=1e-13, atol=1e-300)
+    s.close()
+
+
 @pytest.mark.parametrize("name", ["pulse", "pulse_vrot"])
 def test_pulse_loglike_over_a_wide_range_of_units(name):
     """The pulse likelihoods take sum ln y as the logarithm of a running product split into mantissa and
     exponent, and the quotients d / y two points at a time over a common denominator (pt_device.h
-    LogProdT, terms_lp): products of pairs of numerators and denominators must stay inside fp64's range.
-    The same spectrum in other units -- frequencies in units 1e6 times smaller or larger (the lifetime
-    scaled with them), heights and data 1e60 times smaller or larger -- against the oracle, which adds a
-    gsl_sf_log per point: 1e-12 as everywhere, ragged length, one and four waves per chain."""
+    LogProdT, terms_lp): products of pairs of numerators and denominators must stay inside fp64's range --
+    and where they do not, the lane keeps the smallest exponent they reach, a non-finite sum tells the
+    rest, and the wave takes its share again in the reference's own operation order (Model::term_ref).
+    The same spectrum in other units -- frequencies in units 1e6 and 1e30 times smaller or larger (the
+    lifetime scaled with them: the reference's 2 pi (f - nu) tau has no unit, the kernel's c + (f - nu)^2
+    has), heights and data 1e60 and 1e200 times smaller or larger -- against the oracle, which adds a
+    gsl_sf_log per point: 1e-12 as everywhere, ragged length, one and four waves per chain.  (Heights
+    1e-200 with frequencies 1e30: pulse_vrot's denominator product overflows while the numerators stay
+    finite -- ADVICE r3's case.)"""
     # (1100 points: four passes of the one-wave kernel's long loop -- where pulse_vrot shares a reciprocal
     # among FOUR points and takes the sum again when their products leave the range, as they do at the
     # largest heights here -- and a ragged rest)
@@ -106,8 +130,8 @@ def test_pulse_loglike_over_a_wide_range_of_units(name):
     beta = rs.uniform(0.05, 1.0, len(base))
     heights = [3, 5] if name == "pulse" else [4, 6]
     freqs = [2, 4] if name == "pulse" else [2, 3, 5]                  # (pulse_vrot: vrot, fa, fb)
-    for sf in (1e-6, 1.0, 1e6):
-        for sh in (1e-60, 1.0, 1e60):
+    for sf in (1e-30, 1e-6, 1.0, 1e6, 1e30):
+        for sh in (1e-200, 1e-60, 1.0, 1e60, 1e200):
             data = w.data.copy()
             data[:, 0] *= sf
             data[:, 1] *= sh
@@ -605,7 +629,7 @@ def test_large_configs_size_independent_properties(name, n_chain, n_data, n_swap
         prob, prior = orc.loglike(w.model, a.params[c], w.data, beta=a.beta[c])
         # prob belongs to the last accepted point = current params unless a swap moved params since
         if a.swapcount[max(c - 1, 0):c + 1].sum() == 0:
-            assert abs(a.prob[c] - prob) <= 1e-11 * abs(prob), (c, a.prob[c], prob)
+            assert abs(a.prob[c] - prob) <= 1e-12 * abs(prob), (c, a.prob[c], prob)
 
 
 def test_circular_parameters_wrap_like_the_reference():

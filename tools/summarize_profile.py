@@ -117,9 +117,19 @@ def main():
         entries.append({"tag": tag + "_counters.json", "source": out["command"] + ", MI355X", "kernel": out.get("kernel"),
                         "workload_key": key, "waves_per_chain": bl["waves_per_chain"],
                         "hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "correction": out.get("hbm_correction"),
-                        "valu_wave_insts_per_launch": out.get("valu_wave_insts_per_launch")})
+                        "valu_wave_insts_per_launch": out.get("valu_wave_insts_per_launch"),
+                        # bench.py compares this with the sources it runs on (profile_kernel_sources_changed)
+                        "kernel_sources_sha1": _bench_module().kernel_sources_sha1()})
         json.dump(entries, open(reg, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("kernel", "registers", "hbm_bytes_per_launch", "sq_ratios") if k in out}, indent=1))
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("apemost_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 if __name__ == "__main__":
