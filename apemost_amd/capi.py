@@ -16,6 +16,7 @@ FLAG_SINGLE_ROUND_LAUNCHES, FLAG_COOPERATIVE_LAUNCH, FLAG_TWO_BARRIER_STEP = 1, 
 # the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP, -DADAPT)
 FLAG_PROPOSAL_LOGISTIC, FLAG_PROPOSAL_UNIFORM, FLAG_RANDOMSWAP, FLAG_ADAPT = 8, 16, 32, 64
 FLAG_TEST_REFUSE_COOPERATIVE, FLAG_TEST_WITHHOLD_PUBLISH = 128, 256   # test hooks (include/apemost_hip.h)
+FLAG_RWM = 512
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_CALIBRATION = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -57,7 +58,7 @@ class CalibConfig(C.Structure):
 EXPORTS = [
     "apemost_hip_last_error", "apemost_hip_abi_version", "apemost_hip_device_count",
     "apemost_hip_device_info", "apemost_hip_create", "apemost_hip_destroy", "apemost_hip_synchronize",
-    "apemost_hip_stream", "apemost_hip_waves_per_chain", "apemost_hip_launch_policy", "apemost_hip_set_chain_offset", "apemost_hip_set_data", "apemost_hip_set_state",
+    "apemost_hip_stream", "apemost_hip_waves_per_chain", "apemost_hip_launch_policy", "apemost_hip_user_model_compile_seconds", "apemost_hip_set_chain_offset", "apemost_hip_set_data", "apemost_hip_set_state",
     "apemost_hip_get_state", "apemost_hip_set_round", "apemost_hip_get_round", "apemost_hip_calc_model",
     "apemost_hip_loglike", "apemost_hip_launch_round", "apemost_hip_launch_rounds", "apemost_hip_max_rounds_per_launch",
     "apemost_hip_launch_round_for", "apemost_hip_run", "apemost_hip_samples_alloc",
@@ -88,10 +89,14 @@ def lib():
     # one this library links).  If torch is going to be used for device memory / RCCL plumbing it
     # must be loaded FIRST so that the dynamic linker resolves our DT_NEEDED to the copy already
     # in the process; two runtimes in one process cannot both open the GPU.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # APEMOST_NO_TORCH=1: the caller will not use torch in this process (bench.py --no-torch, the profile
+    # scripts): nothing to order, and the process then holds ONE HIP / HSA runtime -- under rocprofv3,
+    # torch's bundled runtime next to the tool's was what aborted at exit (profiles/README.md).
+    if not os.environ.get("APEMOST_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise ApemostHipError(ERR_NO_DEVICE, "%s not built; run `python -m apemost_amd.build`" % path)
@@ -154,6 +159,7 @@ def lib():
                                       C.POINTER(C.c_uint32)]
     L.apemost_hip_rng_attempts.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64,
                                            C.c_int32, _dp, _dp, C.POINTER(C.c_int32), _dp]
+    L.apemost_hip_user_model_compile_seconds.argtypes = [vp, _dp]
     L.apemost_hip_timer_begin.argtypes = [vp]
     L.apemost_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float), _up]
     _lib = L

@@ -80,6 +80,55 @@ __global__ void pt_adapt_kernel(DevArrays d, double target) {
     }
 }
 
+// adapt() of -DRWM (src/parallel_tempering.c:268-281 + rmw_adapt_stepwidth, src/markov_chain.c:342-367) around
+// ONE more step of the ordinary round kernel: `pre` keeps what that step must not be seen to have changed (the
+// log-posterior before it, the best point), `post` puts the best point and n_iter back and moves the step widths.
+// keep: [n][2 + n_par] = prob, prob_best, params_best.  One thread per chain; `half` = the half of the
+// double-buffered state the chain currently lives in.
+__global__ void pt_rwm_pre_kernel(DevArrays d, int half, double *keep) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n)
+        return;
+    const int n = d.np, row = c + 1;
+    double *k = keep + (size_t)c * (2 + n);
+    k[0] = d.prob(half)[row];
+    k[1] = d.prob_best(half)[row];
+    for (int p = 0; p < n; p++)
+        k[2 + p] = d.params_best(half)[(size_t)row * n + p];
+}
+
+__global__ void pt_rwm_post_kernel(DevArrays d, ChainShape sh, int half, const double *keep, double target) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n)
+        return;
+    const int n = d.np, row = c + 1;
+    const double *k = keep + (size_t)c * (2 + n);
+    d.prob_best(half)[row] = k[1];
+    for (int p = 0; p < n; p++)
+        d.params_best(half)[(size_t)row * n + p] = k[2 + p];
+    const u64 n_iter = d.n_iter()[c] - 1; // (no mcmc_check behind the extra step)
+    d.n_iter()[c] = n_iter;
+    double alpha = exp(d.prob(half)[row] - k[0]);
+    if (alpha > 1)
+        alpha = 1;
+    const u64 tick = d.ticks()[c] - 1; // the extra step's
+    const u64 g = (u64)(sh.chain_offset + c);
+    for (int p = 0; p < n; p++) {
+        const size_t i = (size_t)c * n + p;
+        const double scale = d.pmax()[i] - d.pmin()[i];
+        const double lo = 0.0000001 * scale, hi = 1000000 * scale;
+        const uint4 b = philox_block(sh.seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)n, (tick << kTickShift) | (u64)(1 + p / 4));
+        const unsigned int w = (p & 3) == 0 ? b.x : (p & 3) == 1 ? b.y : (p & 3) == 2 ? b.z : b.w;
+        double step = d.step()[i];
+        step += u32_to_uniform(w) / sqrt((double)n_iter) * (alpha - target) * scale;
+        if (step < lo)
+            step = lo;
+        if (step > hi)
+            step = hi;
+        d.step()[i] = step;
+    }
+}
+
 // Sample rows [n_steps][n_chains][n_par+2] -> what a sink writes, for the kept steps skip, skip + thin, ...
 // layout 0: the record of the C host's binary sink (apemost_amd/host/src/parallel_tempering.c): the
 //   parameter vectors of chains 0..n_param_chains-1, then (prob, prob - prior) of every chain;
@@ -254,9 +303,11 @@ struct apemost_hip_sampler {
     } cal;
     unsigned big_lds_set; // bit w: the LDS opt-in of the w-wave kernels has been made
     // APEMOST_MODEL_USER: the kernels of the user's likelihood, compiled by hiprtc at create time
+    // (indexed by the waves per chain of the two-phase kernels: 1, 2, 4, 8 -- a user likelihood is an
+    // arbitrary function of the data sum, so the one-barrier kernels' threshold form is not for it)
     struct {
         hipModule_t module;
-        hipFunction_t round, calibrate, calc_model, loglike;
+        hipFunction_t round[9], calibrate[9], calc_model[9], loglike[9];
     } user;
     double *edge_out, *edge_in;  // edge records for in-process shard exchanges (created on first use)
     hipEvent_t ev_exported, ev_imported;
@@ -268,6 +319,9 @@ struct apemost_hip_sampler {
                          // non-default proposal law or swap schedule is asked for (pt_device.h)
     bool cooperative;    // multi-round launches through hipLaunchCooperativeKernel
     bool handoff_failed; // an in-launch hand-off timed out once: single-round launches from then on
+    double user_compile_seconds; // hiprtc's time for this sampler's user model (0: taken from the process's cache)
+    double *rwm_keep;            // APEMOST_HIP_FLAG_RWM: what the extra step of a round must not be seen to change
+    bool in_rwm;
 };
 
 extern "C" const char *apemost_hip_last_error(void) { return g_last_error.c_str(); }
@@ -352,7 +406,7 @@ static int choose_waves(const apemost_hip_config &c) {
     // The pulse likelihood with more than three modes -- a loop over the modes that reads its parameters
     // from LDS as it goes, a longer chain per point than the others -- is the exception: eight waves up
     // to 256 chains (256 x 1024: 1.51 vs 1.41e8, 128 x 1024: 9.0 vs 8.2e7 in round 2; pulse_vrot and
-    // sine3 stay with four: 8.9 vs 8.4e7 and 1.05 vs 1.03e8 at 128 x 1024; tools/gpu_exp_w8.sh).  Up
+    // sine3 stay with four: 8.9 vs 8.4e7 and 1.05 vs 1.03e8 at 128 x 1024; tools/experiments/gpu_exp_w8.sh).  Up
     // to three modes the spectrum is taken over a common denominator since round 3 (16 instead of 46
     // instructions per point) and four waves do more: 64 / 128 / 256 / 512 x 1024 5.14 / 11.2 / 23.6 /
     // 35.5e7 against 5.01 / 10.9 / 21.5 / 4.8e7 with eight (profiles/r03_pulse_waves.txt).
@@ -412,11 +466,13 @@ static void release(apemost_hip_sampler *s) {
     delete s;
 }
 
-// ---- APEMOST_MODEL_USER: the user's likelihood compiled into the one-wave kernels at run time ----
+// ---- APEMOST_MODEL_USER: the user's likelihood compiled into the two-phase kernels at run time ----
 // hiprtc is loaded on demand (a sampler of a built-in model never needs it).  The translation unit is
 // "#include pt_kernels.h" -- the same kernel templates this library was built from -- followed by the
 // user's file, which defines the two functions Model<APEMOST_MODEL_USER> calls; the four kernels a
-// one-wave sampler launches are named as template instantiations and fetched by their lowered names.
+// sampler launches, for workgroups of 1, 2, 4 and 8 wavefronts per chain (round 4: the reference's
+// ladders are <= 99 chains, where one wave per chain leaves most of the chip idle), are named as template
+// instantiations and fetched by their lowered names.
 namespace {
 struct HipRtc {
     void *lib;
@@ -487,10 +543,13 @@ static void source_dirs(std::string &csrc, std::string &inc) {
 // phase (the one that checks the device model against the host plugin, one per shard, the one-chain
 // twin of the single-chain API) and compiles once.
 namespace {
+constexpr int kUserShapes = 4;
+constexpr int kUserWaves[kUserShapes] = {1, 2, 4, 8};
 struct UserModelCode {
     std::string key;
     std::vector<char> code;
-    std::string lowered[4];
+    std::string lowered[4 * kUserShapes];
+    double compile_seconds;
 };
 std::vector<UserModelCode> g_user_models;
 std::mutex g_user_models_lock;
@@ -498,10 +557,14 @@ std::mutex g_user_models_lock;
 
 static int user_model_load(apemost_hip_sampler *s, const UserModelCode &m) {
     HIP_TRY(hipModuleLoadData(&s->user.module, m.code.data()));
-    HIP_TRY(hipModuleGetFunction(&s->user.round, s->user.module, m.lowered[0].c_str()));
-    HIP_TRY(hipModuleGetFunction(&s->user.calibrate, s->user.module, m.lowered[1].c_str()));
-    HIP_TRY(hipModuleGetFunction(&s->user.calc_model, s->user.module, m.lowered[2].c_str()));
-    HIP_TRY(hipModuleGetFunction(&s->user.loglike, s->user.module, m.lowered[3].c_str()));
+    for (int k = 0; k < kUserShapes; k++) {
+        const int w = kUserWaves[k];
+        HIP_TRY(hipModuleGetFunction(&s->user.round[w], s->user.module, m.lowered[4 * k + 0].c_str()));
+        HIP_TRY(hipModuleGetFunction(&s->user.calibrate[w], s->user.module, m.lowered[4 * k + 1].c_str()));
+        HIP_TRY(hipModuleGetFunction(&s->user.calc_model[w], s->user.module, m.lowered[4 * k + 2].c_str()));
+        HIP_TRY(hipModuleGetFunction(&s->user.loglike[w], s->user.module, m.lowered[4 * k + 3].c_str()));
+    }
+    s->user_compile_seconds = m.compile_seconds;
     return APEMOST_HIP_OK;
 }
 
@@ -525,12 +588,16 @@ static int user_model_build(apemost_hip_sampler *s) {
     hiprtcProgram prog = nullptr;
     if (rtc.create(&prog, src.c_str(), "apemost_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(APEMOST_HIP_ERR_RUNTIME, "hiprtcCreateProgram failed");
-    char names[4][128];
+    char names[4 * kUserShapes][128];
     const int km = s->kmodel, base = APEMOST_MODEL_USER;
-    snprintf(names[0], sizeof names[0], "apemost::pt_round_kernel<%d, 1, false, false>", km);
-    snprintf(names[1], sizeof names[1], "apemost::pt_calibrate_kernel<%d, 1, false, false>", km);
-    snprintf(names[2], sizeof names[2], "apemost::pt_calc_model_kernel<%d, 1, false>", base);
-    snprintf(names[3], sizeof names[3], "apemost::pt_loglike_kernel<%d, 1, false>", base);
+    for (int k = 0; k < kUserShapes; k++) {
+        const int w = kUserWaves[k];
+        const char *prod = has_producer(w) ? "true" : "false";
+        snprintf(names[4 * k + 0], sizeof names[0], "apemost::pt_round_kernel<%d, %d, false, %s>", km, w, prod);
+        snprintf(names[4 * k + 1], sizeof names[0], "apemost::pt_calibrate_kernel<%d, %d, false, %s>", km, w, prod);
+        snprintf(names[4 * k + 2], sizeof names[0], "apemost::pt_calc_model_kernel<%d, %d, false>", base, w);
+        snprintf(names[4 * k + 3], sizeof names[0], "apemost::pt_loglike_kernel<%d, %d, false>", base, w);
+    }
     for (auto &n : names)
         rtc.add_name(prog, n);
     hipDeviceProp_t prop;
@@ -546,6 +613,7 @@ static int user_model_build(apemost_hip_sampler *s) {
     }
     const std::string arch = std::string("--offload-arch=") + prop.gcnArchName, i1 = "-I" + csrc, i2 = "-I" + inc;
     const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", i1.c_str(), i2.c_str(), "-I/opt/rocm/include"};
+    const auto t_compile = std::chrono::steady_clock::now();
     const hiprtcResult cr = rtc.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     if (cr != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -554,15 +622,16 @@ static int user_model_build(apemost_hip_sampler *s) {
         if (n)
             rtc.log(prog, &log[0]);
         rtc.destroy(&prog);
-        return fail(APEMOST_HIP_ERR_INVALID, "device model %s does not compile:\n%.400s", s->cfg.device_model_source, log.c_str());
+        return fail(APEMOST_HIP_ERR_INVALID, "device model %s does not compile:\n%s", s->cfg.device_model_source, log.c_str());
     }
     UserModelCode m;
     m.key = key;
+    m.compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_compile).count();
     size_t code_bytes = 0;
     rtc.code_size(prog, &code_bytes);
     m.code.resize(code_bytes);
     rtc.code(prog, m.code.data());
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 4 * kUserShapes; i++) {
         const char *low = nullptr;
         if (rtc.lowered(prog, names[i], &low) != HIPRTC_SUCCESS || !low) {
             rtc.destroy(&prog);
@@ -642,10 +711,10 @@ static int create_body(apemost_hip_sampler *s) {
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
         // the round kernel this sampler's stepping launches use: one barrier per step where that
         // variant exists (8 likelihood waves per chain), the classic two-phase step otherwise
-        s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
+        s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP) && !s->user.module;
         int b_lds = 0, b_plain = 0;
         if (s->user.module) {
-            HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&b_plain, s->user.round, kWave, s->lds_fixed_bytes));
+            HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&b_plain, s->user.round[s->waves], s->waves * kWave, s->lds_fixed_bytes));
         } else {
         if (s->lds_data)
             HIP_TRY(round_occupancy<true>(s->kmodel, s->waves, s->producers, s->one_barrier,
@@ -661,7 +730,7 @@ static int create_body(apemost_hip_sampler *s) {
             s->resident_plain = true;
         }
         s->resident_ok = s->resident_lds || s->resident_plain;
-        s->cooperative = (cfg->flags & APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH) && prop.cooperativeLaunch;
+        s->cooperative = (cfg->flags & APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH) && prop.cooperativeLaunch && !s->user.module;
         if (!s->resident_ok && prop.cooperativeLaunch && s->one_barrier) {
             // (the one-barrier kernels only: their steps take a microsecond and a launch per round
             // costs a multiple of that; 2048 one-wave chains of config 5 would fit too, but a round
@@ -681,7 +750,7 @@ static int create_body(apemost_hip_sampler *s) {
         }
         // -DADAPT: adapt() sits between a round's steps and its swap attempt and runs as a launch
         // of its own (pt_adapt_kernel), so every round is a launch
-        if (cfg->flags & (APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_ADAPT))
+        if (cfg->flags & (APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_ADAPT | APEMOST_HIP_FLAG_RWM))
             s->resident_ok = false;
     }
     return APEMOST_HIP_OK;
@@ -710,7 +779,7 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     if (cfg->flags & ~(APEMOST_HIP_FLAG_SINGLE_ROUND_LAUNCHES | APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH |
                        APEMOST_HIP_FLAG_TWO_BARRIER_STEP | APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC |
                        APEMOST_HIP_FLAG_PROPOSAL_UNIFORM | APEMOST_HIP_FLAG_RANDOMSWAP | APEMOST_HIP_FLAG_ADAPT |
-                       APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE | APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH))
+                       APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE | APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH | APEMOST_HIP_FLAG_RWM))
         return fail(APEMOST_HIP_ERR_INVALID, "unknown bits in flags: 0x%x", (unsigned)cfg->flags);
     if ((cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC) && (cfg->flags & APEMOST_HIP_FLAG_PROPOSAL_UNIFORM))
         return fail(APEMOST_HIP_ERR_INVALID, "PROPOSAL_LOGISTIC and PROPOSAL_UNIFORM are alternatives");
@@ -738,8 +807,10 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     case APEMOST_MODEL_USER:
         if (!cfg->device_model_source || !*cfg->device_model_source)
             return fail(APEMOST_HIP_ERR_INVALID, "APEMOST_MODEL_USER needs device_model_source (include/apemost_device_model.h)");
-        if (cfg->waves_per_chain > 1 || cfg->lds_policy == 1)
-            return fail(APEMOST_HIP_ERR_INVALID, "a user-supplied model runs in the one-wave kernels and reads the data rows by index");
+        if (cfg->lds_policy == 1)
+            return fail(APEMOST_HIP_ERR_INVALID, "a user-supplied model reads the data rows by index, through L2: they are not staged in LDS");
+        if (cfg->waves_per_chain == 6)
+            return fail(APEMOST_HIP_ERR_INVALID, "a user-supplied device model runs with 1, 2, 4 or 8 waves per chain");
         break;
     default:
         return fail(APEMOST_HIP_ERR_UNSUPPORTED, "unknown device model %d", cfg->model);
@@ -769,7 +840,10 @@ extern "C" int apemost_hip_create(const apemost_hip_config *cfg, apemost_hip_sam
     s->ev_exported = s->ev_imported = nullptr;
     s->h_word = nullptr;
     s->handoff_failed = false;
-    s->waves = cfg->model == APEMOST_MODEL_USER ? 1 : choose_waves(*cfg);
+    s->waves = choose_waves(*cfg);
+    s->user_compile_seconds = 0;
+    s->rwm_keep = nullptr;
+    s->in_rwm = false;
     if (s->waves == 6 && (cfg->flags & (APEMOST_HIP_FLAG_PROPOSAL_LOGISTIC | APEMOST_HIP_FLAG_PROPOSAL_UNIFORM |
                                         APEMOST_HIP_FLAG_RANDOMSWAP))) {
         delete s;
@@ -840,6 +914,14 @@ extern "C" int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, i
         *waves = s->waves;
     if (data_in_lds)
         *data_in_lds = s->lds_data ? 1 : 0;
+    return APEMOST_HIP_OK;
+}
+
+extern "C" int apemost_hip_user_model_compile_seconds(apemost_hip_sampler *s, double *seconds) {
+    CHECK_S(s);
+    if (!s->user.module || !seconds)
+        return fail(APEMOST_HIP_ERR_INVALID, "not a sampler of a user-supplied device model");
+    *seconds = s->user_compile_seconds;
     return APEMOST_HIP_OK;
 }
 
@@ -1003,13 +1085,15 @@ static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const
     if (coop && (s->cfg.flags & APEMOST_HIP_FLAG_TEST_REFUSE_COOPERATIVE)) // test hook: see the header
         return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: cooperative launch refused (test hook)");
     if (s->user.module) {
-        // the kernels of a user-supplied model live in a run-time module: one wave per chain, data through L2
-        hipFunction_t f = kind == K_ROUND ? s->user.round : kind == K_CALIB ? s->user.calibrate
-                          : kind == K_CALC ? s->user.calc_model : kind == K_EVAL ? s->user.loglike : nullptr;
-        if (!f || waves != 1 || lds_data || coop)
+        // the kernels of a user-supplied model live in a run-time module: the two-phase step, data through L2
+        hipFunction_t f = nullptr;
+        if (waves >= 1 && waves <= 8)
+            f = kind == K_ROUND ? s->user.round[waves] : kind == K_CALIB ? s->user.calibrate[waves]
+                : kind == K_CALC ? s->user.calc_model[waves] : kind == K_EVAL ? s->user.loglike[waves] : nullptr;
+        if (!f || lds_data || coop)
             return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: no such kernel for a user-supplied model");
         void *params[] = {const_cast<void *>(args)};
-        const hipError_t e = hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, kWave, 1, 1, (unsigned)op.lds, s->stream, params, nullptr);
+        const hipError_t e = hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)(waves * kWave), 1, 1, (unsigned)op.lds, s->stream, params, nullptr);
         if (e != hipSuccess)
             return fail(APEMOST_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
         return APEMOST_HIP_OK;
@@ -1194,7 +1278,31 @@ static int launch_round_impl(apemost_hip_sampler *s, uint32_t n_rounds, uint32_t
     }
     if (rc)
         return rc;
-    if ((s->cfg.flags & APEMOST_HIP_FLAG_ADAPT) && n_steps > 0 && which < 0) {
+    if ((s->cfg.flags & APEMOST_HIP_FLAG_RWM) && n_steps > 0 && which < 0 && !s->in_rwm) {
+        // a round of run_sampler has stepped (n_rounds is 1 here): adapt()'s RWM block before its ADAPT block
+        // and before the swap attempt.  The chain now lives in the other half of the state; the extra step is
+        // an ordinary launch of one step (no rows, the pending swap attempt left pending).
+        if (!s->rwm_keep && (rc = dev_alloc(s, &s->rwm_keep, (size_t)s->cfg.n_chains * (2 + s->cfg.n_par))))
+            return rc;
+        const dim3 grid((s->cfg.n_chains + 255) / 256), block(256);
+        const double target = s->cfg.adapt_target != 0 ? s->cfg.adapt_target : 0.5;
+        const u64 round_before = s->round;
+        s->cur ^= 1;
+        s->launches++;
+        hipLaunchKernelGGL(pt_rwm_pre_kernel, grid, block, 0, s->stream, s->d, s->cur, s->rwm_keep);
+        HIP_TRY(hipGetLastError());
+        s->in_rwm = true;
+        rc = launch_round_impl(s, 1, 1, 0, -1, nullptr);
+        s->in_rwm = false;
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL(pt_rwm_post_kernel, grid, block, 0, s->stream, s->d, s->sh, s->cur, (const double *)s->rwm_keep, target);
+        HIP_TRY(hipGetLastError());
+        s->cur ^= 1; // (the bookkeeping below flips it back: the state is where the extra step left it)
+        s->launches--;
+        s->round = round_before;
+    }
+    if ((s->cfg.flags & APEMOST_HIP_FLAG_ADAPT) && n_steps > 0 && which < 0 && !s->in_rwm) {
         // a round of run_sampler has stepped: adapt() before its swap attempt (n_rounds is 1 here)
         const double target = s->cfg.adapt_target != 0 ? s->cfg.adapt_target : 0.5;
         hipLaunchKernelGGL(pt_adapt_kernel, dim3((s->cfg.n_chains + 255) / 256), dim3(256), 0, s->stream, s->d, target);
@@ -1572,10 +1680,11 @@ static CalibShape calib_shape(const apemost_hip_sampler *s, int n_active) {
     CalibShape g;
     apemost_hip_config c = s->cfg;
     c.n_chains = n_active;
-    g.waves = s->user.module ? 1 : choose_waves(c);
+    g.waves = choose_waves(c);
     if (!s->user.module && !built(s->kmodel, g.waves))
         g.waves = s->waves; // (development builds hold only some shapes)
-    g.one_barrier = has_one_barrier(g.waves) && s->kmodel < kVariantModel && !(s->cfg.flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP);
+    g.one_barrier = has_one_barrier(g.waves) && s->kmodel < kVariantModel && !(s->cfg.flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP) &&
+                    !s->user.module;
     const size_t bytes = g.one_barrier ? ob_lds_bytes(s, true) : classic_lds_bytes(s, g.waves, true);
     g.lds_data = !s->user.module && bytes <= 160 * 1024 - 1024 && c.lds_policy != 2 && (c.lds_policy == 1 || choose_lds(c, bytes));
     // A segment of about a quarter of a second: likelihood evaluations a chain gets through in that

@@ -38,7 +38,7 @@ __host__ __device__ constexpr int cand_slots(int waves) { return waves > 8 ? wav
 __host__ __device__ constexpr bool has_producer(int waves) { return waves >= 4; }
 // The one-barrier round kernel (pt_onebarrier.h) exists for 4 and 8 likelihood waves per chain
 // (+ owner + three candidate producers: workgroups of 8 and 12 waves).  Measured on one MI355X
-// (steps/s, one-barrier 4 / one-barrier 8 / two-phase 4; tools/gpu_exp_ob4.sh):
+// (steps/s, one-barrier 4 / one-barrier 8 / two-phase 4; tools/experiments/gpu_exp_ob4.sh):
 //   simplesin  128 x  1024 (n_swap 15): 1.85e8 / 1.66e8 / 1.27e8     64 x 1024: 0.99e8 / 0.88e8
 //   simplesin  256 x  1024 (n_swap  7): 3.18e8 / 1.67e8 / 2.37e8     128 x 4096: 9.2e7 / 8.8e7
 //   pulse      256 x  1024 (n_swap  1): 7.84e7 /   -    / 7.81e7     128 x 16384: 2.43e7 / 2.60e7
@@ -440,7 +440,7 @@ __device__ __forceinline__ u64 rounds_restarting(const E &e, const RoundArgs &a,
 }
 
 template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_round_ob_kernel(const RoundArgs a) {
+__global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_round_ob_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA> e;
     const int c = blockIdx.x;
@@ -498,6 +498,27 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
             }
         }
         OB_STAMP_FLUSH;
+    } else if (e.is_helper()) {
+        // (APEMOST_OB_HELPER_WAVE) the helper alone: the barrier sequence of a producer, helper_step per step
+        e.setup_lanes(a.sh, c);
+        e.setup_helper(a.d, a.sh, c);
+        __syncthreads();
+        int p = 0;
+        for (unsigned r = 0; r < a.n_rounds; r++) {
+            if ((r & 63) == 0)
+                restart = rounds_restarting(e, a, c, r);
+            if ((restart >> (r & 63)) & 1) {
+                p = 0;
+                __syncthreads();
+            }
+            for (unsigned s = 0; s < a.n_steps; s++) {
+                if (e.redraw_pending(p))
+                    __syncthreads();
+                e.helper_step(p);
+                __syncthreads();
+                p ^= 1;
+            }
+        }
     } else {
         // the others wait for this wave at every barrier and it has little to issue: let it go first
 #ifndef APEMOST_OWNER_PRIO
@@ -961,7 +982,7 @@ void pt_calibrate_kernel(const CalibArgs a) {
 // parameter vectors as ever.  The proposal of parameter p+1 does not depend on the outcome of
 // parameter p's step, only the rest of the vector does, so both variants carry the same attempt.
 template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_calibrate_ob_kernel(const CalibArgs a) {
+__global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_calibrate_ob_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA> e;
     const int slot = a.list[blockIdx.x];
@@ -1002,6 +1023,24 @@ __global__ __launch_bounds__((LW + 4) * kWave) __attribute__((amdgpu_waves_per_e
                 if (e.redraw_pending(p))
                     __syncthreads();
                 e.producer_step(p);
+                __syncthreads();
+                p ^= 1;
+            }
+        }
+    } else if (e.is_helper()) {
+        e.setup_lanes(a.sh, c);
+        e.setup_helper(a.d, a.sh, c);
+        __syncthreads();
+        for (;;) {
+            __syncthreads();
+            const int n_steps = __builtin_amdgcn_readfirstlane(*s_steps);
+            if (n_steps == 0)
+                break;
+            int p = 0;
+            for (int s = 0; s < n_steps; s++) {
+                if (e.redraw_pending(p))
+                    __syncthreads();
+                e.helper_step(p);
                 __syncthreads();
                 p ^= 1;
             }
@@ -1160,7 +1199,7 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
         break;
     case K_ROUND_OB:
         if constexpr (has_one_barrier(WAVES)) {
-            const dim3 bo((WAVES + 4) * kWave); // + owner + three candidate producers
+            const dim3 bo(ob_block(MODEL, WAVES)); // + owner + three candidate producers (+ helper)
             if (coop) {
                 void *params[] = {const_cast<void *>(args)};
                 return hipLaunchCooperativeKernel((const void *)pt_round_ob_kernel<MODEL, WAVES, LDS>, g, bo, params,
@@ -1185,7 +1224,7 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
     case K_CALIB_OB:
         // (the default proposal law and swap schedule only: the variants calibrate on the two-phase step)
         if constexpr (has_one_barrier(WAVES) && MODEL < kVariantModel) {
-            const dim3 bo((WAVES + 4) * kWave);
+            const dim3 bo(ob_block(MODEL, WAVES));
             hipLaunchKernelGGL((pt_calibrate_ob_kernel<MODEL, WAVES, LDS>), g, bo, lds, st, *(const CalibArgs *)args);
         } else {
             return hipErrorInvalidDeviceFunction;
@@ -1313,7 +1352,7 @@ struct OccupancyOp {
         if constexpr (has_one_barrier(WAVES)) {
             if (one_barrier)
                 return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS>,
-                                                                    (WAVES + 4) * kWave, lds_bytes);
+                                                                    ob_block(MODEL, WAVES), lds_bytes);
         }
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
                                                             block_threads(WAVES, kCanProduce), lds_bytes);

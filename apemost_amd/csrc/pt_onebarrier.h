@@ -77,12 +77,19 @@ struct ObThreshold<APEMOST_MODEL_SIMPLESIN> {
 template <>
 struct ObThreshold<APEMOST_MODEL_SINE3> : ObThreshold<APEMOST_MODEL_SIMPLESIN> {};
 
+#ifndef APEMOST_OB_SPLIT
+#define APEMOST_OB_SPLIT 1
+#endif
 template <>
 struct ObThreshold<APEMOST_MODEL_PULSE> {
-    static constexpr bool kSplit = true;
+    static constexpr bool kSplit = APEMOST_OB_SPLIT != 0;
     double inv_beta;
     __device__ __forceinline__ void init(const ModelConsts &, double beta) { inv_beta = 1.0 / beta; }
     // prob_new = prior + -beta (p1 + S) > T  <=>  S < (prior - T) / beta - p1 = (prior / beta - p1) - T / beta
+    template <class M>
+    __device__ __forceinline__ double s_max(double T, const M &, double prior_new, double p1) const { // (!kSplit: the owner alone)
+        return (prior_new - T) * inv_beta - p1;
+    }
     __device__ __forceinline__ double x_part(double prior_new, double p1) const { return prior_new * inv_beta - p1; }
     __device__ __forceinline__ double y_part(double T) const { return T * inv_beta; }
     static __device__ __forceinline__ double limit(double x, double y) { return x - y; }
@@ -106,6 +113,17 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
     } while (0)
 #endif
 
+// APEMOST_OB_HELPER_WAVE: the helper of the kSplit models as a ninth (LW + 5th) wavefront of the workgroup instead
+// of a duty of the candidate producers
+#ifndef APEMOST_OB_HELPER_WAVE
+#define APEMOST_OB_HELPER_WAVE 0
+#endif
+__host__ __device__ constexpr bool ob_has_helper_wave(int model) {
+    return APEMOST_OB_HELPER_WAVE != 0 && APEMOST_OB_SPLIT != 0 &&
+           (model % kVariantModel == APEMOST_MODEL_PULSE || model % kVariantModel == APEMOST_MODEL_PULSE_VROT);
+}
+__host__ __device__ constexpr int ob_block(int model, int lw) { return (lw + 4 + (ob_has_helper_wave(model) ? 1 : 0)) * kWave; }
+
 template <int MODEL, int LW, bool LDS_DATA>
 struct ObEngine {
 #ifdef APEMOST_STAMPS
@@ -114,7 +132,8 @@ struct ObEngine {
 #endif
     static constexpr int kLikThreads = LW * kWave;
     static constexpr int kProducers = 3;
-    static constexpr int kBlock = (LW + 1 + kProducers) * kWave;
+    static constexpr int kBlock = ob_block(MODEL, LW);
+    static constexpr bool kHelperWave = ob_has_helper_wave(MODEL); // the helper's duty in a wavefront of its own
     static constexpr int kWide = LW < 8 ? 4 : 2;
     static constexpr int kShortChain = LW >= APEMOST_SHORT_CHAIN_WAVES ? 1 : LW >= APEMOST_EVEN_ODD_WAVES ? 2 : 0;
     static constexpr bool kVariants = MODEL >= kVariantModel; // see kVariantModel (pt_device.h)
@@ -127,7 +146,8 @@ struct ObEngine {
     int tid;       // likelihood thread index (likelihood waves)
     __device__ __forceinline__ bool is_lik() const { return hw < LW; }
     __device__ __forceinline__ bool is_owner() const { return hw == LW; }
-    __device__ __forceinline__ bool is_producer() const { return hw > LW; }
+    __device__ __forceinline__ bool is_producer() const { return hw > LW && hw <= LW + kProducers; }
+    __device__ __forceinline__ bool is_helper() const { return kHelperWave && hw == LW + kProducers + 1; }
 
     int n_par, n_data;
     int Q, grp, qidx, n_cand_lanes;
@@ -332,7 +352,39 @@ struct ObEngine {
             m.set_lean(false);
         m.set_consts(consts);
     }
+#ifndef APEMOST_OB_HELPER_BOTH
+#define APEMOST_OB_HELPER_BOTH 1
+#endif
+    // APEMOST_OB_HELPER_BOTH: the priors of BOTH prepared rows, requested with the step's first LDS reads and
+    // taken side by side (Model::prior_two), the decision beside them, a select at the end -- the decision's
+    // LDS round trip, tree and compare (~300 ticks) leave the front of the logarithm's chain
     __device__ __forceinline__ void helper_step(int parity) {
+#if APEMOST_OB_HELPER_BOTH
+        const double *ra = s_prop(parity, 0), *rr = s_prop(parity, 1);
+        double part[LW];
+        const double *sp = s_part(parity);
+#pragma unroll
+        for (int w = 0; w < LW; w++)
+            part[w] = sp[w];
+        const double limit = ObThreshold<kBase>::limit(*s_thx(parity), *s_thr(parity));
+        const double p1a = ra[1], p1r = rr[1];
+        double pa, pr;
+        m.prior_two(ra, rr, n_par, consts, pa, pr);
+#pragma unroll
+        for (int span = 1; span < LW; span *= 2) {
+#pragma unroll
+            for (int w = 0; w + span < LW; w += 2 * span)
+                part[w] += part[w + span];
+        }
+        const bool first = part[0] < limit;
+        const double prior_k = first ? pa : pr;
+        const double x = thr_fn.x_part(prior_k, first ? p1a : p1r);
+        if (lane == 0) {
+            *s_thx(parity ^ 1) = x;
+            *s_pri(parity ^ 1) = prior_k;
+        }
+        return;
+#endif
         const double sum = tree(parity);
         const double limit = ObThreshold<kBase>::limit(*s_thx(parity), *s_thr(parity));
         const double *row = s_prop(parity, sum < limit ? 0 : 1);
@@ -346,7 +398,7 @@ struct ObEngine {
     }
     __device__ __forceinline__ void producer_step(int parity) {
         if (pipe_phase == 0) {
-            if constexpr (kSplit)
+            if constexpr (kSplit && !kHelperWave)
                 helper_step(parity);
             pipe = cand_begin(pipe_tick);
             pipe_phase = 1;
@@ -693,17 +745,17 @@ struct ObEngine {
             __builtin_amdgcn_wave_barrier();
             par_val = cand() ? row[grp] : 0.0;
         }
-        if constexpr (kSplit)
-            m.load_offset(row, n_par); // (finish_known_prior reads the additive parameter, nothing else)
+        if constexpr (Model<kBase>::kHasPrior)
+            m.load_offset(row, n_par); // (prior_only, offset and finish_known_prior read the heights and the additive parameter, nothing else)
         else
             m.load(row, n_par, x_abs_max);
         OB_SEG(2); // the proposal in flight
     }
     // candidates of the next tick: published by the barrier that opened this step; requested with the
     // step's first batch of LDS reads (APEMOST_HOIST_CAND: config 2 2.036 -> 2.066e8 steps/s, config 4
-    // 2.29 -> 2.33e8, tools/gpu_exp_hoist.sh), not where the proposals need them
+    // 2.29 -> 2.33e8, tools/experiments/gpu_exp_hoist.sh), not where the proposals need them
     __device__ __forceinline__ double2 owner_fetch_next_cand() const { return s_cand(tick + 1)[lane]; }
-    // MERGED: both prepared proposals through attempts2() (measured, tools/gpu_exp_hoist.sh with
+    // MERGED: both prepared proposals through attempts2() (measured, tools/experiments/gpu_exp_hoist.sh with
     // APEMOST_ATTEMPTS2: the calibration kernels 3-7 % faster and config 4's round kernel 2.345 -> 2.375e8
     // steps/s with it, config 2's round kernel 2.07 -> 2.04e8: the round kernel of the models without a
     // prior keeps the two calls)
@@ -721,10 +773,17 @@ struct ObEngine {
         }
         OB_SEG(3); // next candidates, both prepared proposals
         // S_max of the step in flight (kSplit: the chain's half of it; the helper adds the proposal's)
-        OB_SEG(4); // (the prior of the proposal in flight: the helper's since round 4)
+        double prior_new = 0;
+        if constexpr (Model<kBase>::kHasPrior && !kSplit) {
+            prior_new = m.prior_only(consts);
+            prior_inflight = prior_new;
+        }
+        OB_SEG(4); // the prior of the proposal in flight (kSplit: the helper's since round 4)
         const double lu = read_lane(cand_y, 63);
         if constexpr (kSplit)
             thr = thr_fn.y_part(prob + lu);
+        else if constexpr (Model<kBase>::kHasPrior)
+            thr = thr_fn.s_max(prob + lu, m, prior_new, m.offset());
         else
             thr = thr_fn.s_max(prob + lu, m, 0.0, 0.0);
         if (lane == 0) {

@@ -197,7 +197,8 @@ class HipShardEngine:
     def __init__(self, sampler, torch):
         self.s, self.torch = sampler, torch
         self.n_rec = 3 + 2 * sampler.n_par
-        self._ext = torch.cuda.ExternalStream(sampler.stream)
+        # (torch None: a single rank without torch in the process -- bench.py --no-torch; no exchange ever happens)
+        self._ext = torch.cuda.ExternalStream(sampler.stream) if torch is not None else None
 
     def swap_pair(self, round_):
         return self.s.swap_pair(round_)
@@ -212,7 +213,8 @@ class HipShardEngine:
     def fence(self):
         """everything queued on the engine's stream and on torch's streams of this device is done"""
         self.s.synchronize()
-        self.torch.cuda.synchronize()
+        if self.torch is not None:
+            self.torch.cuda.synchronize()
 
     def edge_export(self, side):
         buf = self.torch.empty(self.n_rec, dtype=self.torch.float64, device="cuda")

@@ -19,14 +19,18 @@
 
 /* Compile-time variants of the reference.  -DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM
  * (src/mcmc_gettersetter.c:290-305), -DRANDOMSWAP (src/parallel_tempering_interaction.c:130-131)
- * and -DADAPT (src/parallel_tempering.c:282-301) are carried to the device engine as
+ * and -DADAPT, -DRWM (src/parallel_tempering.c:268-301) are carried to the device engine as
  * apemost_hip_config.flags (src/apemost_bridge.c).  What the engine does not implement refuses
  * to build rather than silently sample something else. */
 #if defined(PROPOSAL_LOGISTIC) && defined(PROPOSAL_UNIFORM)
 #error "PROPOSAL_LOGISTIC and PROPOSAL_UNIFORM are alternatives"
 #endif
-#ifdef RWM
-#error "RWM: per-step adaptive step widths are not implemented by the MI355X engine (nor compilable in the reference)"
+/* -DRWM (src/parallel_tempering.c:268-281, src/markov_chain.c:342-367): carried as APEMOST_HIP_FLAG_RWM since
+ * round 4 -- the reference's own call site does not compile (a two-argument call of markov_chain_step);
+ * include/apemost_hip.h states the semantics the engine gives it.  MINIMAL_STEPWIDTH / MAXIMAL_STEPWIDTH keep
+ * their defaults on the device. */
+#if defined(RWM) && (defined(MINIMAL_STEPWIDTH) || defined(MAXIMAL_STEPWIDTH))
+#error "RWM: the device engine clamps step widths to the reference's default [1e-7, 1e6] x range"
 #endif
 #if defined(CALIBRATE_MULTILIN) || defined(CALIBRATE_QUADRATIC) || defined(CALIBRATE_ALTERNATE)
 #error "alternate calibrators are not implemented by the MI355X engine (default markov_chain_calibrate_orig only)"

@@ -177,9 +177,12 @@ static apemost_hip_sampler *create_sampler(const mcmc *m, int model, unsigned in
 #ifdef ADAPT
     if (run_ladder)
         cfg.flags |= APEMOST_HIP_FLAG_ADAPT;
-#else
-    (void)run_ladder;
 #endif
+#ifdef RWM
+    if (run_ladder)
+        cfg.flags |= APEMOST_HIP_FLAG_RWM;
+#endif
+    (void)run_ladder;
     cfg.adapt_target = TARGET_ACCEPTANCE_RATE;
     cfg.device_model_source = model == APEMOST_MODEL_USER ? getenv("APEMOST_DEVICE_MODEL_SRC") : NULL;
     apemost_hip_or_die(apemost_hip_create(&cfg, &s), "apemost_hip_create");

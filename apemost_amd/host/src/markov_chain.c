@@ -155,12 +155,13 @@ void markov_chain_calibrate(mcmc *m, const unsigned int burn_in_iterations, doub
 #endif
 void rmw_adapt_stepwidth(mcmc *m, const double prob_old) {
     const double ratio = exp(get_prob(m) - prob_old);
-    const double pull = ((ratio < 1 ? ratio : 1) - TARGET_ACCEPTANCE_RATE) / sqrt(m->n_iter);
+    const double excess = (ratio < 1 ? ratio : 1) - TARGET_ACCEPTANCE_RATE;
     unsigned int p;
     for (p = 0; p < get_n_par(m); p++) {
         const double range = get_params_max_for(m, p) - get_params_min_for(m, p);
         const double narrowest = MINIMAL_STEPWIDTH * range, widest = MAXIMAL_STEPWIDTH * range;
-        double width = get_steps_for(m, p) + get_next_uniform_random(m) * pull * range;
+        /* the reference's association, U / sqrt(n) * excess * range: the device kernel and the oracle round alike */
+        double width = get_steps_for(m, p) + get_next_uniform_random(m) / sqrt(m->n_iter) * excess * range;
         width = width < narrowest ? narrowest : width;
         width = width > widest ? widest : width;
         set_steps_for(m, width, p);

@@ -104,6 +104,13 @@ class HipSampler:
         return w.value, bool(l.value)
 
     @property
+    def user_model_compile_seconds(self):
+        """hiprtc's time for this sampler's device model (0: the process had compiled the same source before)"""
+        t = C.c_double(0)
+        capi.check(self.L.apemost_hip_user_model_compile_seconds(self._h, C.byref(t)))
+        return t.value
+
+    @property
     def launch_policy(self):
         """(one-barrier kernel, cooperative multi-round launches, rounds one launch may hold)"""
         ob, co, mr = C.c_int32(0), C.c_int32(0), C.c_int32(0)
@@ -148,8 +155,10 @@ class HipSampler:
         (torch.zeros fills it on torch's current stream) must be complete before the first kernel
         writes rows into it, or the fill may land on top of them."""
         if d_samples and d_samples != getattr(self, "_last_samples", 0):
-            import torch
-            torch.cuda.current_stream().synchronize()
+            import sys
+            torch = sys.modules.get("torch")    # (a process without torch has no torch buffer to wait for)
+            if torch is not None and torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
         self._last_samples = d_samples
 
     def launch_round(self, n_steps, apply_swap, d_samples=0):

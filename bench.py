@@ -77,6 +77,9 @@ def parse():
                          "(RCCL refuses two ranks on one device)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal of N > 1 on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even with one rank")
+    ap.add_argument("--no-torch", action="store_true",
+                    help="one rank without torch in the process: sample rows in a buffer of the engine's own, one HIP "
+                         "runtime (what the profile scripts run: tools/profile_config.sh)")
     a = ap.parse_args()
     for k, v in CONFIGS[a.config].items():
         if getattr(a, k, None) is None:
@@ -115,6 +118,29 @@ def spawn_ranks(n):
                     q.terminate()
         time.sleep(0.05)
     return rc
+
+
+class EngineRows:
+    """sample rows [rounds][doubles per round] in a device buffer of the engine's own (--no-torch): what
+    ShardedLadder.run_sampler needs of a tensor -- slices along the rounds and their device address"""
+
+    def __init__(self, sampler, rounds, steps_per_round, base=None, first=0):
+        import ctypes as C
+        self.s, self.rounds, self.steps, self.first = sampler, rounds, steps_per_round, first
+        self.per_round = steps_per_round * sampler.n_chains * (sampler.n_par + 2)
+        if base is None:
+            from apemost_amd import capi
+            p = C.c_void_p()
+            capi.check(sampler.L.apemost_hip_samples_alloc(sampler._h, rounds * steps_per_round, C.byref(p)))
+            base = p.value
+        self.base = base
+
+    def __getitem__(self, sl):
+        lo, hi, _ = sl.indices(self.rounds)
+        return EngineRows(self.s, hi - lo, self.steps, self.base, self.first + lo)
+
+    def data_ptr(self):
+        return self.base + 8 * self.first * self.per_round
 
 
 def host_cores():
@@ -211,18 +237,30 @@ def main():
 
     if os.environ.get("APEMOST_BENCH_TEST_FAIL_RANK") == str(rank):   # test hook (tests/test_gpu_bench_ranks.py)
         raise SystemExit(7)
-    import torch
-    import torch.distributed as dist
+    if a.no_torch:
+        if world > 1 or a.force_dist:
+            raise SystemExit("--no-torch is for one rank")
+        os.environ["APEMOST_NO_TORCH"] = "1"
+        torch = dist = None
+    else:
+        import torch
+        import torch.distributed as dist
     from apemost_amd import capi, workloads as wl
     from apemost_amd.sampler import HipSampler, get_chain_beta
     from apemost_amd.state import LadderState
     from apemost_amd.distributed import HipShardEngine, ShardedLadder
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     if a.same_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if torch is None:
+        try:
+            dev_name, dev_cus, _ = capi.device_info(local_rank)
+        except capi.ApemostHipError as e:
+            raise SystemExit("bench.py needs an MI355X; there is no CPU path (%s)" % e)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+        torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_dist
     comm_device = "cuda" if a.backend == "nccl" else "cpu"   # where the bench's own small collectives live
     if use_dist:
@@ -278,8 +316,10 @@ def main():
     acc0 = s.get_state()
     waves, lds = s.geometry
     samples = None
-    if not a.no_samples:
+    if not a.no_samples and torch is not None:
         samples = torch.zeros((R, n_swap, n_local, w.n_par + 2), dtype=torch.float64, device="cuda")
+    elif not a.no_samples:
+        samples = EngineRows(s, R, n_swap)
     eng = HipShardEngine(s, torch)
     ladder = ShardedLadder(eng, n_global, lo, n_local, rank, world, dist if use_dist else None)
 
@@ -292,7 +332,8 @@ def main():
 
     def sync_all():
         s.synchronize()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
@@ -368,9 +409,12 @@ def main():
     # step costs is instructions -- one wave64 VALU instruction occupies its SIMD for four cycles,
     # integer or fp64 -- and, on ladders smaller than the chip, the CUs that have no chain.  `frac` is
     # against the whole chip; `frac_on_occupied_simds` says how busy the SIMDs that hold a chain are.
-    props = torch.cuda.get_device_properties(local_rank)
-    clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
-    cus = props.multi_processor_count
+    if torch is not None:
+        props = torch.cuda.get_device_properties(local_rank)
+        clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+        cus = props.multi_processor_count
+    else:
+        clock_hz, cus = 2400e6, dev_cus     # (MI355X_MICROARCH.md: 2.4 GHz peak engine clock)
     waves_per_wg = waves + 4 if one_barrier else waves
     cus_occupied = min(cus, n_local)
     simds_occupied = min(4 * cus, n_local * min(4, waves_per_wg))
@@ -422,6 +466,18 @@ def main():
     if calibration is not None:
         # the calibration's likelihood evaluations per second against the round kernel's on the same ladder
         calibration["rate_vs_round_kernel"] = calibration["evaluations_per_s"] / (value / world)
+        # its own issue roofline: SQ_INSTS_VALU of every calibration launch of the profiled run of this command
+        # over their summed durations (profiles/*_calib_counters.json, registered by tools/summarize_profile.py)
+        ckey = "%s/%d/%d/calibration" % (w.name, n_local, w.n_data)
+        try:
+            for pmc in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
+                if pmc.get("workload_key") == ckey:
+                    calibration.update({"valu_issue_frac_profiled": pmc.get("valu_issue_frac"),
+                                        "valu_wave_insts_profiled": pmc.get("valu_wave_insts"),
+                                        "profile": pmc.get("tag"),
+                                        "profile_kernel_sources_changed": pmc.get("kernel_sources_sha1") != kernel_sources_sha1()})
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
         out["calibration"] = calibration
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:

@@ -130,7 +130,17 @@ enum {
      * up after a few thousand polls instead of eight million -- the partner's wait runs out, the
      * launch's error word is raised, apemost_hip_synchronize reports it, and the sampler issues one
      * round per launch from then on */
-    APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH = 256
+    APEMOST_HIP_FLAG_TEST_WITHHOLD_PUBLISH = 256,
+    /* -DRWM: adapt()'s other block (src/parallel_tempering.c:268-281; it does not compile in the reference:
+     * `markov_chain_step(chains[i], 0)` passes two arguments to a function of one).  As restated here: after
+     * the steps of every round and before its swap attempt every chain keeps its log-posterior, takes ONE
+     * more markov_chain_step -- accept / reject counters and the RNG tick move, but no mcmc_check follows it:
+     * no sample row, n_iter and the best point stay what the round's own steps left -- and
+     * rmw_adapt_stepwidth (src/markov_chain.c:342-367) moves every step width by
+     * U / sqrt(n_iter) * (min(1, exp(prob - prob_old)) - adapt_target) * (max - min), clamped to
+     * [1e-7, 1e6] * (max - min); U = word p % 4 of block (tick << 24) | (1 + p / 4) of the accept slot.
+     * Every round is a launch of its own (as with APEMOST_HIP_FLAG_ADAPT, which runs after it). */
+    APEMOST_HIP_FLAG_RWM = 512
 };
 
 typedef struct {
@@ -216,6 +226,10 @@ int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, int *data_in
  * rounds one launch may hold (1: the grid is not resident, a cooperative launch was refused, or a
  * hand-off timed out) */
 int apemost_hip_launch_policy(apemost_hip_sampler *s, int32_t *one_barrier, int32_t *cooperative, int32_t *max_rounds);
+/* APEMOST_MODEL_USER: seconds hiprtc took to compile this sampler's device model (the kernels of the
+ * user's likelihood for 1, 2, 4 and 8 waves per chain); 0 when the process had compiled the same source
+ * before.  Fails for the built-in models. */
+int apemost_hip_user_model_compile_seconds(apemost_hip_sampler *s, double *seconds);
 /* move the shard along the ladder (single-chain API of the C host layer: the chain's ladder
  * position selects its RNG streams); offset + n_chains must stay <= n_chains_global */
 int apemost_hip_set_chain_offset(apemost_hip_sampler *s, int64_t chain_offset);

@@ -787,6 +787,49 @@ void orc_adapt(orc_state *s, int c) {
         orc_reset_accept_rejects(s, c);
 }
 
+/* adapt() with -DRWM (src/parallel_tempering.c:268-281): per chain, once per round between the n_swap
+ * steps and tempering_interaction:  prob_old = get_prob; markov_chain_step; rmw_adapt_stepwidth(prob_old).
+ * (The reference's call `markov_chain_step(chains[i], 0)` has one argument too many and does not compile;
+ * the function has ONE parameter, src/markov_chain.h, and that is what is restated.)  No mcmc_check follows
+ * that step: the best point and n_iter are what the round's own steps left.
+ * rmw_adapt_stepwidth (src/markov_chain.c:342-367): alpha = min(1, exp(prob - prob_old)) with the chain's
+ * prob AFTER the step (a rejected step leaves prob = prob_old: alpha = 1); every step width
+ *   step += U / sqrt(n_iter) * (alpha - TARGET_ACCEPTANCE_RATE) * (max - min),
+ * clamped to [MINIMAL_STEPWIDTH, MAXIMAL_STEPWIDTH] * (max - min) = [1e-7, 1e6] * range (:335-340);
+ * U = get_next_uniform_random, one per parameter, in parameter order. */
+double orc_rwm_uniform(uint64_t seed, uint64_t chain_global, int n_par, uint64_t tick, int p) {
+    const uint64_t subseq = chain_global * ORC_STREAMS_PER_CHAIN + (uint64_t)n_par;
+    const uint64_t block = (tick << ORC_TICK_SHIFT) | (uint64_t)(1 + p / 4);
+    return orc_philox_at(seed, subseq, 4 * block + (uint64_t)(p % 4)) / 4294967296.0;
+}
+
+void orc_rwm(orc_state *s, orc_rng *r, int c) {
+    const int n = s->n_par;
+    const double prob_old = s->prob[c];
+    const uint64_t tick = r->kind == ORC_RNG_STREAMS ? r->ticks[c] : 0;
+    double alpha;
+    int p;
+    orc_markov_chain_step(s, r, c);
+    alpha = exp(s->prob[c] - prob_old);
+    if (alpha > 1)
+        alpha = 1;
+    for (p = 0; p < n; p++) {
+        const size_t k = (size_t)c * n + p;
+        const double scale = s->pmax[k] - s->pmin[k];
+        const double lo = 0.0000001 * scale, hi = 1000000 * scale;
+        const double u = r->kind == ORC_RNG_STREAMS
+                             ? orc_rwm_uniform(r->seed, (uint64_t)(s->chain_offset + c), n, tick, p)
+                             : orc_uniform(r);
+        double step = s->step[k];
+        step += u / sqrt(s->n_iter[c]) * (alpha - s->adapt_target) * scale;
+        if (step < lo)
+            step = lo;
+        if (step > hi)
+            step = hi;
+        s->step[k] = step;
+    }
+}
+
 void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n_swap,
                      double *samples, int n_threads) {
     uint64_t round;
@@ -807,6 +850,9 @@ void orc_run_sampler(orc_state *s, orc_rng *r, uint64_t n_rounds, unsigned int n
             for (c = 0; c < s->n_chain; c++)
                 run_chain_round(s, r, c, round, n_swap, samples);
         }
+        if (s->rwm) /* (adapt(): the RWM block precedes the ADAPT block) */
+            for (c = 0; c < s->n_chain; c++)
+                orc_rwm(s, r, c);
         if (s->adapt)
             for (c = 0; c < s->n_chain; c++)
                 orc_adapt(s, c);

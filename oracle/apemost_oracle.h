@@ -127,6 +127,7 @@ typedef struct {
     int randomswap;         /* -DRANDOMSWAP, src/parallel_tempering_interaction.c:130-131 */
     int adapt;              /* -DADAPT, src/parallel_tempering.c:282-301 */
     double adapt_target;    /* TARGET_ACCEPTANCE_RATE, src/define_defaults.h:77-79 */
+    int rwm;                /* -DRWM, src/parallel_tempering.c:268-281 + src/markov_chain.c:342-367 */
 } orc_state;
 
 /* calibration knobs (src/define_defaults.h:24-86, src/markov_chain.h:25-32) */
@@ -199,6 +200,12 @@ void orc_run_steps(orc_state *s, orc_rng *r, unsigned int n_steps, double *sampl
 /* -DADAPT step-width nudging of one chain at the end of a round (orc_run_sampler calls it for
  * every chain when s->adapt is set) */
 void orc_adapt(orc_state *s, int chain);
+/* adapt() with -DRWM for one chain: one more markov_chain_step, then rmw_adapt_stepwidth with the log-posterior
+ * the chain had before it (src/parallel_tempering.c:275-280, src/markov_chain.c:342-367) */
+void orc_rwm(orc_state *s, orc_rng *r, int chain);
+/* rmw_adapt_stepwidth's n_par uniforms in STREAMS mode: word p % 4 of block (tick << 24) | (1 + p / 4) of the
+ * accept slot, tick = the extra step's */
+double orc_rwm_uniform(uint64_t seed, uint64_t chain_global, int n_par, uint64_t tick, int p);
 
 /* samples: [n_rounds*n_swap][n_chain][n_par+2] = params.., prob, prob-prior ; may be NULL.
  * n_threads > 1 is only meaningful with ORC_RNG_STREAMS. */

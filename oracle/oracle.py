@@ -44,7 +44,7 @@ class _State(C.Structure):
                 ("beta", _dp), ("prob", _dp), ("prior", _dp), ("prob_best", _dp),
                 ("accept", _up), ("reject", _up), ("n_iter", _up), ("swapcount", _up),
                 ("proposal", C.c_int), ("randomswap", C.c_int), ("adapt", C.c_int),
-                ("adapt_target", C.c_double)]
+                ("adapt_target", C.c_double), ("rwm", C.c_int)]
 
 
 class CalibCfg(C.Structure):
@@ -93,6 +93,9 @@ def lib():
                                        C.c_double, _dp]
         L.orc_jump_attempt.restype = C.c_int
         L.orc_adapt.argtypes = [C.POINTER(_State), C.c_int]
+        L.orc_rwm.argtypes = [C.POINTER(_State), C.POINTER(_Rng), C.c_int]
+        L.orc_rwm_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
+        L.orc_rwm_uniform.restype = C.c_double
         L.orc_accept_log_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
         L.orc_accept_log_uniform.restype = C.c_double
         L.orc_loglike.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
@@ -176,6 +179,7 @@ class Ladder:
         self.randomswap = 0                 # -DRANDOMSWAP
         self.adapt = 0                      # -DADAPT
         self.adapt_target = 0.5             # TARGET_ACCEPTANCE_RATE
+        self.rwm = 0                        # -DRWM
         z2 = lambda dt: np.zeros((n_chain, n_par), dtype=dt)
         z1 = lambda dt: np.zeros((n_chain,), dtype=dt)
         self.params, self.params_best, self.step = z2(np.float64), z2(np.float64), z2(np.float64)
@@ -215,6 +219,7 @@ class Ladder:
         st.circular = self.circular
         st.proposal, st.randomswap, st.adapt = int(self.proposal), int(self.randomswap), int(self.adapt)
         st.adapt_target = float(self.adapt_target)
+        st.rwm = int(self.rwm)
         for n in _F64:
             a = getattr(self, n)
             assert a.flags.c_contiguous and a.dtype == np.float64, n
@@ -332,6 +337,11 @@ def step(ladder, rng, chain):
 def step_for(ladder, rng, chain, p):
     st = ladder.c_state()
     lib().orc_markov_chain_step_for(C.byref(st), C.byref(rng.c), chain, p)
+
+
+def rwm(ladder, rng, chain):
+    st = ladder.c_state()
+    lib().orc_rwm(C.byref(st), C.byref(rng.c), chain)
 
 
 def check_best(ladder, chain):

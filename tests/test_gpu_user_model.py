@@ -1,5 +1,5 @@
 """A likelihood that is not one of the built-in device models, supplied as device source and compiled
-by hiprtc into the engine's one-wave kernels (include/apemost_device_model.h, APEMOST_MODEL_USER;
+by hiprtc into the engine's two-phase kernels (1, 2, 4 and 8 waves per chain since round 4) (include/apemost_device_model.h, APEMOST_MODEL_USER;
 SURVEY 8(f4): the plugin surface for apps/simplesin2.c, apps/normal.c, apps/bernoulli_example.c and
 for functions registered with set_function).  Checked against oracle models that restate those apps
 (oracle/apemost_oracle.c ll_sine2 / ll_normal / ll_bernoulli)."""
@@ -47,7 +47,7 @@ CASES = {"simplesin2": (_sine2, orc.MODEL_SINE2), "bernoulli_example": (_bernoul
          "normal": (_normal, orc.MODEL_NORMAL)}
 
 
-def _pair(name, n_chain, seed):
+def _pair(name, n_chain, seed, waves=0):
     make, omodel = CASES[name]
     data, box = make()
     n_par = len(box["start"])
@@ -60,20 +60,23 @@ def _pair(name, n_chain, seed):
     for c in range(n_chain):
         orc.calc_model(lad, c)
     st.prob[:], st.prior[:] = lad.prob, lad.prior
-    s = HipSampler(wl.MODEL_USER, n_par, n_chain, data, seed=seed, device_model_source=os.path.join(MODELS, name + ".hip"))
+    s = HipSampler(wl.MODEL_USER, n_par, n_chain, data, seed=seed, waves_per_chain=waves,
+                   device_model_source=os.path.join(MODELS, name + ".hip"))
     s.set_state(st)
     return s, st, lad, orc.Rng(orc.RNG_STREAMS, seed, lad), data, box
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_user_model_likelihood_sampling_and_calibration_match_oracle(name):
-    """the device source of each of the reference's three other example apps: calc_model at random
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_user_model_likelihood_sampling_and_calibration_match_oracle(name, waves):
+    """the device source of each of the reference's three other example apps, in workgroups of 1, 2, 4 and 8
+    wavefronts per chain (the two-phase kernels; 4 and 8 with the candidate producers): calc_model at random
     points (rel 1e-12), a run with swaps (rows rel 1e-9, counters exact), and the calibration (status
     and sweep counts exact)"""
     import torch
     n_chain = 6
-    s, st, lad, rng, data, box = _pair(name, n_chain, seed=61)
-    assert s.geometry == (1, False) and not s.launch_policy[0]
+    s, st, lad, rng, data, box = _pair(name, n_chain, seed=61, waves=waves)
+    assert s.geometry == (waves, False) and not s.launch_policy[0]
     rs = np.random.RandomState(8)
     pts = box["pmin"] + (box["pmax"] - box["pmin"]) * rs.uniform(0.05, 0.95, (40, len(box["start"])))
     betas = rs.uniform(0.05, 1, 40)
@@ -185,3 +188,42 @@ def test_c_application_with_its_own_likelihood_runs_through_a_device_model(tmp_p
     np.testing.assert_allclose(got[:, 0], lad.beta, rtol=1e-9)
     np.testing.assert_allclose(got[:, 1:3], lad.step, rtol=1e-9)
     np.testing.assert_allclose(got[:, 3:5], lad.params, rtol=1e-9)
+
+
+def test_small_user_model_ladder_gets_several_waves_per_chain_and_runs_faster_for_it(capsys):
+    """The reference's ladders are <= 99 chains (src/parallel_tempering.c:366): one wave per chain leaves most
+    of the chip idle.  A user model gets the workgroup shape a built-in sine model would get from
+    choose_waves (minus the one-barrier kernel: a user's finish() is an arbitrary function of the data sum)
+    -- 16 chains x 8192 points: eight waves, against one wave per chain at least 4x the steps/s; 16 x 1024:
+    four waves.  Prints the rates and hiprtc's compile time for the 16 kernels of the model."""
+    import time
+    src = os.path.join(MODELS, "simplesin2.hip")
+    rates = {}
+    for n_data, expect in ((8192, 8), (1024, 4)):
+        data, box = _sine2(n_data)
+        n_chain = 16
+        st = LadderState.from_params(n_chain, box["start"], box["pmin"], box["pmax"], (box["pmax"] - box["pmin"]) * 0.03)
+        for waves in (0, 1):
+            s = HipSampler(wl.MODEL_USER, 2, n_chain, data, seed=3, waves_per_chain=waves, device_model_source=src)
+            if waves == 0:
+                assert s.geometry == (expect, False)
+                compile_s = s.user_model_compile_seconds
+            s.set_state(st)
+            s.calc_model(0, n_chain)
+            s.run_sampler(4, 50)
+            s.synchronize()
+            t0 = time.perf_counter()
+            s.run_sampler(200, 50)
+            s.synchronize()
+            rates[(n_data, waves)] = 200 * 50 * n_chain / (time.perf_counter() - t0)
+            final = s.get_state()
+            s.close()
+            if waves == 0:
+                keep = final
+            else:      # same draws, same decisions unless a comparison lands inside the rounding of the data sum
+                assert np.array_equal(final.accept, keep.accept) and np.allclose(final.params, keep.params, rtol=1e-9)
+    with capsys.disabled():
+        print("\n[user model, 16 chains] steps/s: 8192 points %.3g (8 waves) vs %.3g (1 wave); 1024 points %.3g (4 waves) vs "
+              "%.3g (1 wave); hiprtc %.2f s" % (rates[(8192, 0)], rates[(8192, 1)], rates[(1024, 0)], rates[(1024, 1)], compile_s))
+    assert rates[(8192, 0)] >= 4 * rates[(8192, 1)]
+    assert rates[(1024, 0)] >= 1.5 * rates[(1024, 1)]

@@ -143,6 +143,34 @@ def test_adapt_nudges_step_widths_like_the_reference(waves):
     assert not np.allclose(dev2.step, dev.step)
 
 
+@pytest.mark.parametrize("name,waves", [("simplesin", 1), ("simplesin", 4), ("pulse", 4), ("pulse_vrot", 2)])
+def test_rwm_moves_step_widths_like_the_restated_reference(name, waves):
+    """-DRWM (src/parallel_tempering.c:268-281 + rmw_adapt_stepwidth, src/markov_chain.c:342-367; the reference's
+    own call site does not compile, include/apemost_hip.h states what the engine makes of it): every round ends
+    with one more step per chain that moves the counters and the RNG tick but neither n_iter nor the best point
+    nor the sample rows, and with every step width moved by U / sqrt(n_iter) (min(1, exp(dprob)) - target) range.
+    Against the oracle's restatement (orc_rwm): counters, ticks and n_iter exact, widths and rows 1e-9; together
+    with -DADAPT (adapt() runs both blocks, RWM first)."""
+    w = small_workloads()[name]
+    n_chain, n_rounds, n_swap, seed = 6, 90, 4, 77
+    st, lad, rng = make_pair(w, n_chain, seed=seed)
+    lad.rwm, lad.adapt_target = 1, 0.5
+    step0 = st.step.copy()
+    dev, samples = _run(w, st, n_chain, n_rounds, n_swap, waves, seed, flags=capi.FLAG_RWM)
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    assert_match(dev, lad, rng, what="rwm %s waves=%d" % (name, waves))
+    np.testing.assert_allclose(samples, ref, rtol=1e-9, atol=1e-300)
+    assert np.all(dev.n_iter == n_rounds * n_swap) and np.all(dev.ticks == n_rounds * (n_swap + 1))
+    assert np.all(dev.accept + dev.reject == n_rounds * (n_swap + 1))
+    assert not np.allclose(dev.step, step0)
+    if name == "simplesin" and waves == 4:
+        st2, lad2, rng2 = make_pair(w, n_chain, seed=seed)
+        lad2.rwm, lad2.adapt, lad2.adapt_target = 1, 1, 0.3
+        dev2, _ = _run(w, st2, n_chain, 2300, 3, waves, seed, flags=capi.FLAG_RWM | capi.FLAG_ADAPT, adapt_target=0.3)
+        orc.run_sampler(lad2, rng2, 2300, 3)           # 2300 x 4 steps x 4 parameters: past ADAPT's 20000 updates
+        assert_match(dev2, lad2, rng2, what="rwm + adapt")
+
+
 def test_variant_flags_are_validated():
     w = small_workloads()["simplesin"]
     with pytest.raises(capi.ApemostHipError, match="alternatives"):

@@ -44,13 +44,14 @@ def test_example_app_builds_strict(tmp_path):
 
 def test_variant_macros_build_strict_and_rwm_is_refused(tmp_path):
     """the reference's compile-time variants (-DPROPOSAL_LOGISTIC, -DPROPOSAL_UNIFORM, -DRANDOMSWAP,
-    -DADAPT) are accepted on the application's compile line (the bridge turns them into engine
-    flags); -DRWM, which the reference itself cannot compile, stops the build with a message"""
+    -DADAPT, and since round 4 -DRWM) are accepted on the application's compile line (the bridge turns
+    them into engine flags); what the engine does not carry -- the two proposal laws at once, -DRWM with
+    its clamps redefined -- stops the build with a message"""
     build.build_hip()
-    for flags in ("-DPROPOSAL_LOGISTIC -DRANDOMSWAP -DADAPT -DTARGET_ACCEPTANCE_RATE=0.4", "-DPROPOSAL_UNIFORM"):
+    for flags in ("-DPROPOSAL_LOGISTIC -DRANDOMSWAP -DADAPT -DTARGET_ACCEPTANCE_RATE=0.4", "-DPROPOSAL_UNIFORM", "-DRWM -DADAPT"):
         assert os.path.exists(_make(str(tmp_path / "v.exe"), ccflags="-DN_BETA=4 " + flags))
         os.remove(str(tmp_path / "v.exe"))
-    for flags in ("-DRWM", "-DPROPOSAL_LOGISTIC -DPROPOSAL_UNIFORM"):
+    for flags in ("-DRWM -DMINIMAL_STEPWIDTH=0.001", "-DPROPOSAL_LOGISTIC -DPROPOSAL_UNIFORM"):
         with pytest.raises(subprocess.CalledProcessError):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apemost_amd", "host"),
                                    "OUT=" + str(tmp_path / "no.exe"), "CCFLAGS=-DN_BETA=4 " + flags],

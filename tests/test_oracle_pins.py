@@ -320,6 +320,51 @@ def test_adapt_thresholds_and_scaling():
     assert lad.params_accepts[1].sum() == 6000      # below 100000: kept
 
 
+def test_rwm_block_against_a_numpy_restatement():
+    """adapt() with -DRWM (src/parallel_tempering.c:268-281) + rmw_adapt_stepwidth (src/markov_chain.c:342-367):
+    prob_old kept, ONE markov_chain_step (no mcmc_check behind it), then per parameter
+    step += U / sqrt(n_iter) * (min(1, exp(prob - prob_old)) - TARGET) * (max - min), clamped to [1e-7, 1e6] x
+    range.  The oracle's orc_rwm against the same expression in numpy on the oracle's own step, in both RNG modes
+    (GLOBAL_MT: the n_par uniforms are the next n_par of the one stream, as get_next_uniform_random draws them;
+    STREAMS: words p % 4 of blocks (tick << 24) | (1 + p / 4) of the accept slot), the clamps included."""
+    from apemost_amd import workloads as wl
+    from tests.helpers import make_pair
+    w = wl.simplesin(n_data=32, n_chain=3)
+    for kind in (orc.RNG_STREAMS, orc.RNG_GLOBAL_MT):
+        st, lad, _ = make_pair(w, 3, seed=9, init_prob=True)
+        _, twin, _ = make_pair(w, 3, seed=9, init_prob=True)
+        rng, rng2 = orc.Rng(kind, 9, lad), orc.Rng(kind, 9, twin)
+        lad.adapt_target = twin.adapt_target = 0.4
+        lad.n_iter[:] = twin.n_iter[:] = (7, 1000, 123456)
+        lad.step[2, 1] = twin.step[2, 1] = 1.2e-7 * (w.pmax[1] - w.pmin[1])       # next to the lower clamp
+        lad.step[1, 0] = twin.step[1, 0] = 1e6 * (w.pmax[0] - w.pmin[0])          # on the upper one
+        for c in range(3):
+            prob_old, tick = twin.prob[c], (int(rng2.ticks[c]) if kind == orc.RNG_STREAMS else 0)
+            orc.rwm(lad, rng, c)
+            orc.step(twin, rng2, c)
+            alpha = min(1.0, float(np.exp(twin.prob[c] - prob_old)))
+            for p in range(4):
+                u = (orc.lib().orc_rwm_uniform(9, c, 4, tick, p) if kind == orc.RNG_STREAMS
+                     else orc.lib().orc_uniform(ctypes_byref(rng2)))
+                scale = w.pmax[p] - w.pmin[p]
+                v = twin.step[c, p] + u / np.sqrt(float(twin.n_iter[c])) * (alpha - 0.4) * scale
+                twin.step[c, p] = min(max(v, 0.0000001 * scale), 1000000 * scale)
+            assert np.array_equal(lad.step[c], twin.step[c]), (kind, c)
+            assert lad.prob[c] == twin.prob[c] and np.array_equal(lad.params[c], twin.params[c])
+            assert lad.n_iter[c] == twin.n_iter[c] and lad.accept[c] + lad.reject[c] == 1
+        assert lad.step[2, 1] >= 1e-7 * (w.pmax[1] - w.pmin[1]) and lad.step[1, 0] <= 1e6 * (w.pmax[0] - w.pmin[0])
+        if kind == orc.RNG_STREAMS:
+            assert np.array_equal(rng.ticks, rng2.ticks)
+            # the four uniforms of a block are its four words, the fifth parameter's is word 0 of the next block
+            words = orc.philox_stream(9, 2 * 256 + 4, 8, start=4 * ((5 << 24) | 1))
+            assert [orc.lib().orc_rwm_uniform(9, 2, 4, 5, p) for p in range(4)] == [x / 2.0 ** 32 for x in words[:4]]
+
+
+def ctypes_byref(rng):
+    import ctypes as C
+    return C.byref(rng.c)
+
+
 # ---- the reference's other example likelihoods (checkers of the user-supplied device models) -------------
 def test_oracle_restatements_of_the_other_example_apps_against_numpy():
     """ll_sine2 / ll_normal / ll_bernoulli of the oracle (apps/simplesin2.c:12-34, apps/normal.c:8-34,

@@ -13,7 +13,10 @@ cfg=$1; tag=$2; shift 2
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-common="--config $cfg --cpu-seconds 0 --steps 10 --warmup 2 $*"
+# --no-torch: the profiled process holds one HIP / HSA runtime (with torch's bundled one beside the tool's, the
+# passes of config 4 -- cooperative launches -- aborted inside exit(), profiles/README.md); -e again since then
+set -e
+common="--config $cfg --cpu-seconds 0 --steps 4 --warmup 1 --no-torch $*"
 python3 bench.py $common > $out/bench_short.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $common > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py $common > $out/fetch.log 2>&1

@@ -52,6 +52,38 @@ def per_launch(rows, kernel, min_us=0.0):
     return out, statistics.median([durs[i] for i in keep]), len(keep)
 
 
+def family_totals(rows, family):
+    """every dispatch of the kernels of one family together: launches, total duration, total SQ_INSTS_VALU, and the
+    same per kernel -- the issue roofline of a PHASE made of many different launches (the calibration:
+    workgroup shapes change as chains finish)"""
+    dur, insts, name = {}, {}, {}
+    for r in rows:
+        k = r["Kernel_Name"]
+        if family not in k:
+            continue
+        i = r["Dispatch_Id"]
+        dur[i] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        name[i] = k
+        if r["Counter_Name"] == "SQ_INSTS_VALU":
+            insts[i] = insts.get(i, 0.0) + float(r["Counter_Value"])
+    if not dur or not insts:
+        return None
+    per = {}
+    for i, k in name.items():
+        e = per.setdefault(k, {"launches": 0, "total_us": 0.0, "valu_wave_insts": 0.0})
+        e["launches"] += 1
+        e["total_us"] += dur[i]
+        e["valu_wave_insts"] += insts.get(i, 0.0)
+    total_us, total_insts = sum(dur.values()), sum(insts.values())
+    peak = 1024 * 2.4e9 / 4      # wave-instructions per second: 1024 SIMDs, one per four cycles (bench.py)
+    for e in per.values():
+        e["valu_issue_frac"] = e["valu_wave_insts"] / (e["total_us"] * 1e-6) / peak
+    return {"launches": len(dur), "total_us": total_us, "valu_wave_insts": total_insts,
+            "valu_issue_frac": total_insts / (total_us * 1e-6) / peak,
+            "note": "SQ_INSTS_VALU summed over every launch of the family / their summed durations / (1024 SIMDs x 2.4 GHz / 4)",
+            "by_kernel": per}
+
+
 def main():
     """summarize_profile.py <tag> <config> [family [suffix]]: family = substring that selects the kernels
     (default pt_round; pt_calibrate for the calibration launches of the same runs), suffix = inserted
@@ -65,7 +97,7 @@ def main():
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
     out = {"config": int(cfg), "tag": tag,
-           "command": "tools/profile_config.sh %s %s  (rocprofv3 ... -- python3 bench.py --config %s --cpu-seconds 0 --steps 10 --warmup 2)" % (cfg, tag, cfg)}
+           "command": "tools/profile_config.sh %s %s  (rocprofv3 ... -- python3 bench.py --config %s --cpu-seconds 0 --steps 4 --warmup 1 --no-torch)" % (cfg, tag, cfg)}
     try:
         out["bench_line"] = json.loads(open(os.path.join(src, "bench_short.json")).read().strip().splitlines()[-1])
     except (OSError, ValueError, IndexError):
@@ -92,6 +124,10 @@ def main():
         # FETCH_SIZE/WRITE_SIZE are in KB; gfx950 tallies wide coalesced reads at half their bytes
         out["hbm_bytes_per_launch"] = (2 * f + w) * 1024
         out["hbm_correction"] = "FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B), WRITE_SIZE exact; KB -> bytes"
+    if family != "pt_round":
+        tot = family_totals(counter_rows(os.path.join(src, "sq")), family)
+        if tot:
+            out["phase_issue_roofline"] = tot
     sq = out.get("sq", {}).get("median", {})
     if sq:
         wc = sq.get("SQ_WAVE_CYCLES", 0)
@@ -121,7 +157,17 @@ def main():
                         # bench.py compares this with the sources it runs on (profile_kernel_sources_changed)
                         "kernel_sources_sha1": _bench_module().kernel_sources_sha1()})
         json.dump(entries, open(reg, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("kernel", "registers", "hbm_bytes_per_launch", "sq_ratios") if k in out}, indent=1))
+    # the calibration phase of the same runs: what bench.py quotes as calibration.valu_issue_frac_profiled
+    if family == "pt_calibrate" and bl and "phase_issue_roofline" in out:
+        reg = os.path.join(dst, "pmc_traffic.json")
+        key = "%s/%d/%d/calibration" % (out["bench_line"]["metric"].split(" on ")[1].split(",")[0], bl["chains_per_gpu"], bl["n_data"])
+        entries = [e for e in json.load(open(reg)) if e.get("workload_key") != key]
+        t = out["phase_issue_roofline"]
+        entries.append({"tag": tag + suffix + "_counters.json", "source": out["command"] + ", MI355X", "workload_key": key,
+                        "launches": t["launches"], "seconds_profiled": t["total_us"] * 1e-6, "valu_wave_insts": t["valu_wave_insts"],
+                        "valu_issue_frac": t["valu_issue_frac"], "kernel_sources_sha1": _bench_module().kernel_sources_sha1()})
+        json.dump(entries, open(reg, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("kernel", "registers", "hbm_bytes_per_launch", "sq_ratios", "phase_issue_roofline") if k in out}, indent=1))
 
 
 def _bench_module():
