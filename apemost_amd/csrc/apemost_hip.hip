@@ -557,6 +557,19 @@ std::mutex g_user_models_lock;
 
 static int user_model_load(apemost_hip_sampler *s, const UserModelCode &m) {
     HIP_TRY(hipModuleLoadData(&s->user.module, m.code.data()));
+    {
+        // the headers hiprtc compiled are the ones this library was built from
+        hipDeviceptr_t sym = nullptr;
+        size_t bytes = 0;
+        unsigned long long theirs = 0;
+        if (hipModuleGetGlobal(&sym, &bytes, s->user.module, "apemost_rtc_fingerprint") != hipSuccess || bytes != sizeof theirs)
+            return fail(APEMOST_HIP_ERR_RUNTIME, "the compiled device model has no layout fingerprint: kernel headers older than this library?");
+        HIP_TRY(hipMemcpyDtoH(&theirs, sym, sizeof theirs));
+        if (theirs != kAbiFingerprint)
+            return fail(APEMOST_HIP_ERR_RUNTIME,
+                        "the kernel headers compiled for the device model (APEMOST_HIP_SOURCE_DIR, or csrc/ beside the library) "
+                        "do not match this library: layout fingerprint %llx, library %llx", theirs, kAbiFingerprint);
+    }
     for (int k = 0; k < kUserShapes; k++) {
         const int w = kUserWaves[k];
         HIP_TRY(hipModuleGetFunction(&s->user.round[w], s->user.module, m.lowered[4 * k + 0].c_str()));
@@ -583,8 +596,16 @@ static int user_model_build(apemost_hip_sampler *s) {
     fclose(f);
     std::string csrc, inc;
     source_dirs(csrc, inc);
-    const std::string src = "#define APEMOST_USER_MODEL 1\n#include \"pt_kernels.h\"\n#line 1 \"" +
-                            std::string(s->cfg.device_model_source) + "\"\n" + user + "\n";
+    std::string shown; // the path as a C string literal (#line): backslashes and quotes escaped
+    for (const char *q = s->cfg.device_model_source; *q; q++) {
+        if (*q == '\\' || *q == '"')
+            shown += '\\';
+        if (*q != '\n' && *q != '\r')
+            shown += *q;
+    }
+    const std::string src = "#define APEMOST_USER_MODEL 1\n#include \"pt_kernels.h\"\n#line 1 \"" + shown + "\"\n" + user + "\n";
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->cfg.device)); // (before the program exists: nothing to release on failure)
     hiprtcProgram prog = nullptr;
     if (rtc.create(&prog, src.c_str(), "apemost_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(APEMOST_HIP_ERR_RUNTIME, "hiprtcCreateProgram failed");
@@ -600,8 +621,6 @@ static int user_model_build(apemost_hip_sampler *s) {
     }
     for (auto &n : names)
         rtc.add_name(prog, n);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->cfg.device));
     const std::string key = std::to_string(s->kmodel) + "|" + prop.gcnArchName + "|" + user;
     {
         std::lock_guard<std::mutex> hold(g_user_models_lock);
@@ -1413,8 +1432,14 @@ extern "C" int apemost_hip_samples_pack_read_async(apemost_hip_sampler *s, const
                            (int)layout, d_packed);
         HIP_TRY(hipGetLastError());
     }
-    if (counters)
+    if (counters) {
         HIP_TRY(hipMemcpyAsync(counters, s->d.accept(), 2 * n * sizeof(u64), hipMemcpyDeviceToHost, s->stream));
+        // ... and, behind them, chain 0's parameter vector of the batch's LAST step (n_par doubles): what a
+        // progress line prints, whatever the packing kept
+        if (n_steps > 0)
+            HIP_TRY(hipMemcpyAsync(counters + 2 * n, d_samples + (size_t)(n_steps - 1) * n * (np + 2), np * sizeof(double),
+                                   hipMemcpyDeviceToHost, s->stream));
+    }
     HIP_TRY(hipMemcpyAsync(s->h_word, s->d.timeout_word(), sizeof(u64), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(s->ev_copy, s->stream));
     HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_copy, 0));

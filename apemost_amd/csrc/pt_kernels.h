@@ -419,6 +419,12 @@ void pt_round_kernel(const RoundArgs a) {
 #define OB_STAMP_FLUSH
 #endif
 
+// APEMOST_OWNER_PRIO_PHASE (experiment, round 4): the owner at APEMOST_OWNER_PRIO for the first part of its step only
+// -- up to the decision and bookkeeping (3), up to the proposal in flight (2), up to the prepared proposals (1) --
+// and at priority 0 for the rest: the likelihood wave on its SIMD is the last at the barrier, the owner is not.
+#ifndef APEMOST_OWNER_PRIO_PHASE
+#define APEMOST_OWNER_PRIO_PHASE 0
+#endif
 // The rounds base .. base+63 of this launch whose opening swap attempt involves chain c (bit r - base):
 // lane l draws the pair of round base + l from the replicated swap stream.  A swap attempt touches
 // its two chains only (src/parallel_tempering_interaction.c:99-141): for every other chain the
@@ -500,23 +506,25 @@ __global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_pe
         OB_STAMP_FLUSH;
     } else if (e.is_helper()) {
         // (APEMOST_OB_HELPER_WAVE) the helper alone: the barrier sequence of a producer, helper_step per step
-        e.setup_lanes(a.sh, c);
-        e.setup_helper(a.d, a.sh, c);
-        __syncthreads();
-        int p = 0;
-        for (unsigned r = 0; r < a.n_rounds; r++) {
-            if ((r & 63) == 0)
-                restart = rounds_restarting(e, a, c, r);
-            if ((restart >> (r & 63)) & 1) {
-                p = 0;
-                __syncthreads();
-            }
-            for (unsigned s = 0; s < a.n_steps; s++) {
-                if (e.redraw_pending(p))
+        if constexpr (decltype(e)::kHelperWave) {
+            e.setup_lanes(a.sh, c);
+            e.setup_helper(a.d, a.sh, c);
+            __syncthreads();
+            int p = 0;
+            for (unsigned r = 0; r < a.n_rounds; r++) {
+                if ((r & 63) == 0)
+                    restart = rounds_restarting(e, a, c, r);
+                if ((restart >> (r & 63)) & 1) {
+                    p = 0;
                     __syncthreads();
-                e.helper_step(p);
-                __syncthreads();
-                p ^= 1;
+                }
+                for (unsigned s = 0; s < a.n_steps; s++) {
+                    if (e.redraw_pending(p))
+                        __syncthreads();
+                    e.helper_step(p);
+                    __syncthreads();
+                    p ^= 1;
+                }
             }
         }
     } else {
@@ -565,6 +573,9 @@ __global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_pe
 #endif
                 // one batch of LDS reads: the redraw flag, what the prepared proposals settled on
                 // for my parameter, and (owner_results) the partial sums
+#if APEMOST_OWNER_PRIO_PHASE
+                __builtin_amdgcn_s_setprio(APEMOST_OWNER_PRIO); // (dropped in the step's later part, see below)
+#endif
                 const int pending = *e.s_flag(p);
 #if APEMOST_HOIST_CAND
                 const double2 nx = e.owner_fetch_next_cand(); // (with the step's first batch of LDS reads)
@@ -576,7 +587,13 @@ __global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_pe
                         my_sample += sample_stride;
                 }
                 const bool redraw_pending = __builtin_amdgcn_readfirstlane(pending) != 0;
+#if APEMOST_OWNER_PRIO_PHASE == 3
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 e.owner_choose(p, !open);
+#if APEMOST_OWNER_PRIO_PHASE == 2
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 if (redraw_pending) // rare: a proposal in LDS has just been replaced
                     __syncthreads();
 #if !APEMOST_HOIST_CAND
@@ -1028,21 +1045,23 @@ __global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_pe
             }
         }
     } else if (e.is_helper()) {
-        e.setup_lanes(a.sh, c);
-        e.setup_helper(a.d, a.sh, c);
-        __syncthreads();
-        for (;;) {
+        if constexpr (decltype(e)::kHelperWave) {
+            e.setup_lanes(a.sh, c);
+            e.setup_helper(a.d, a.sh, c);
             __syncthreads();
-            const int n_steps = __builtin_amdgcn_readfirstlane(*s_steps);
-            if (n_steps == 0)
-                break;
-            int p = 0;
-            for (int s = 0; s < n_steps; s++) {
-                if (e.redraw_pending(p))
-                    __syncthreads();
-                e.helper_step(p);
+            for (;;) {
                 __syncthreads();
-                p ^= 1;
+                const int n_steps = __builtin_amdgcn_readfirstlane(*s_steps);
+                if (n_steps == 0)
+                    break;
+                int p = 0;
+                for (int s = 0; s < n_steps; s++) {
+                    if (e.redraw_pending(p))
+                        __syncthreads();
+                    e.helper_step(p);
+                    __syncthreads();
+                    p ^= 1;
+                }
             }
         }
     } else {
@@ -1174,6 +1193,21 @@ __global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_pe
         chain_store(e, a.d, a.sh, c, a.cur, true);
     }
 }
+
+// What the precompiled host code and a run-time compilation of these templates (a user-supplied model,
+// apemost_hip.hip user_model_build) must agree on: the layouts of the kernel arguments and of the LDS carve.
+// The hiprtc module exports the value it was compiled with (apemost_rtc_fingerprint below), the host compares
+// it with its own at load: headers that drifted from the library (APEMOST_HIP_SOURCE_DIR, a stale .so, a
+// development build) are an error, not silently wrong arguments.
+constexpr unsigned long long kAbiFingerprint =
+    (unsigned long long)sizeof(RoundArgs) ^ ((unsigned long long)sizeof(CalibArgs) << 10) ^ ((unsigned long long)sizeof(EvalArgs) << 20) ^
+    ((unsigned long long)sizeof(CalibRec) << 28) ^ ((unsigned long long)kFixedLdsDoubles << 34) ^
+    ((unsigned long long)kObFixedDoubles << 46) ^ ((unsigned long long)kTickShift << 58) ^ 0x4150454d6f535434ull;
+#ifdef APEMOST_USER_MODEL
+} // namespace apemost
+extern "C" __device__ __attribute__((used)) const unsigned long long apemost_rtc_fingerprint = apemost::kAbiFingerprint;
+namespace apemost {
+#endif
 
 #ifndef __HIPCC_RTC__ // (a run-time compilation of a user-supplied model holds the kernels only)
 // ---- launch dispatch over (model, waves, lds) ----

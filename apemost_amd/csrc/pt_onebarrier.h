@@ -77,8 +77,15 @@ struct ObThreshold<APEMOST_MODEL_SIMPLESIN> {
 template <>
 struct ObThreshold<APEMOST_MODEL_SINE3> : ObThreshold<APEMOST_MODEL_SIMPLESIN> {};
 
+// APEMOST_OB_SPLIT = 1 (measured in round 4 and NOT the default, profiles/r04_ob_helper_roles.txt): the prior of the
+// proposal in flight leaves the owner.  On the MI355X box config 4's shard runs 2.30e8 steps/s with the owner
+// computing it (0), 2.14 / 2.16e8 with a candidate producer as helper (decision first / both rows side by
+// side: that producer's Philox step becomes the longest wave of the workgroup, ~2100 of 2140 ticks), 2.28e8 with a
+// ninth wavefront as helper (APEMOST_OB_HELPER_WAVE; the grid then needs a cooperative launch at 256 chains).
+// The owner was not what the step waits for: the likelihood wave that shares the owner's SIMD is (1920-1990
+// ticks busy in every variant against 1650-1720 for its three siblings).
 #ifndef APEMOST_OB_SPLIT
-#define APEMOST_OB_SPLIT 1
+#define APEMOST_OB_SPLIT 0
 #endif
 template <>
 struct ObThreshold<APEMOST_MODEL_PULSE> {
@@ -383,8 +390,7 @@ struct ObEngine {
             *s_thx(parity ^ 1) = x;
             *s_pri(parity ^ 1) = prior_k;
         }
-        return;
-#endif
+#else
         const double sum = tree(parity);
         const double limit = ObThreshold<kBase>::limit(*s_thx(parity), *s_thr(parity));
         const double *row = s_prop(parity, sum < limit ? 0 : 1);
@@ -395,6 +401,7 @@ struct ObEngine {
             *s_thx(parity ^ 1) = x;
             *s_pri(parity ^ 1) = pr;
         }
+#endif
     }
     __device__ __forceinline__ void producer_step(int parity) {
         if (pipe_phase == 0) {
@@ -772,6 +779,9 @@ struct ObEngine {
             fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
         }
         OB_SEG(3); // next candidates, both prepared proposals
+#if defined(APEMOST_OWNER_PRIO_PHASE) && APEMOST_OWNER_PRIO_PHASE == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // S_max of the step in flight (kSplit: the chain's half of it; the helper adds the proposal's)
         double prior_new = 0;
         if constexpr (Model<kBase>::kHasPrior && !kSplit) {

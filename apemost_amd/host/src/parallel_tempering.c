@@ -481,7 +481,8 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
             apemost_hip_or_die(apemost_hip_host_alloc(max_rounds * n_swap * n_local * (n_par + 2) * sizeof(double), &p),
                                "host_alloc");
             h_samples[i][j] = (double *)p;
-            apemost_hip_or_die(apemost_hip_host_alloc(2 * n_local * sizeof(uint64_t), &p), "host_alloc");
+            /* (+ n_par doubles: chain 0's latest point behind the counters of a packed read) */
+            apemost_hip_or_die(apemost_hip_host_alloc((2 * n_local + n_par) * sizeof(uint64_t), &p), "host_alloc");
             h_counts[i][j] = (uint64_t *)p;
         }
     /* One shard and a sink that does not want every row as it is (binary records, thinning): the
@@ -538,11 +539,10 @@ static void run_sampler(mcmc **chains, const unsigned int n_beta, const unsigned
         apemost_swap_round += rounds_now;
         if (iter % PRINT_PROB_INTERVAL == 0) {
             /* chain 0's latest row and counters live in shard 0 */
-            /* (a packed batch holds the kept iterations only: then the latest kept one, whose record
-             * begins with chain 0's parameters wherever it has any) */
+            /* (a packed batch holds the kept iterations only -- an older one, or none: the packed read leaves
+             * chain 0's point after the batch's last step behind the counters) */
             const double *last = !device_pack ? h_samples[k][0] + (n_steps - 1) * (size_t)(lo[1] - lo[0]) * (n_par + 2)
-                                 : h_samples[k][0] + (kept > 0 ? kept - 1 : 0) *
-                                       (sink.binary ? (size_t)sink.n_param_chains * n_par + 2 * (size_t)n_beta : row);
+                                              : (const double *)(h_counts[k][0] + 2 * (lo[1] - lo[0]));
             const uint64_t accept0 = h_counts[k][0][0], reject0 = h_counts[k][0][lo[1] - lo[0]];
             if (dumpflag) {
                 /* a report on request: the ladder as the device holds it now (a batch ahead of

@@ -306,7 +306,10 @@ int apemost_hip_samples_read_async(apemost_hip_sampler *s, const double *d_sampl
  *             (prob, prob - prior) of every chain  -- the record of the C host's binary sink;
  *   layout 1: the kept rows themselves, [n_kept][n_chains][n_par+2].
  * d_packed: DEVICE scratch for the packed batch (apemost_hip_samples_alloc sizes fit), host_packed:
- * pinned; counters and the wait as for apemost_hip_samples_read_async. */
+ * pinned; the wait as for apemost_hip_samples_read_async; counters, if not NULL, receives [2][n_chains]
+ * uint64 as there and BEHIND them n_par doubles: chain 0's parameter vector after the batch's last step
+ * (the reference's progress line prints chain 0's current point, src/parallel_tempering.c:309-318; a
+ * packed batch may have kept an older step, or none) -- (2 n_chains + n_par) * 8 bytes. */
 int apemost_hip_samples_pack_read_async(apemost_hip_sampler *s, const double *d_samples, uint64_t n_steps,
                                         uint64_t skip, uint64_t thin, int32_t n_param_chains, int32_t layout,
                                         double *d_packed, double *host_packed, uint64_t *counters, uint64_t *n_kept);

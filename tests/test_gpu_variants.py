@@ -205,7 +205,7 @@ def test_samples_packed_on_the_device_equal_the_rows_repacked_on_the_host():
     host = C.c_void_p()
     capi.check(L.apemost_hip_host_alloc(ref.nbytes, C.byref(host)))
     packed = torch.zeros(ref.size, dtype=torch.float64, device="cuda")
-    counters = np.zeros(2 * n_chain, dtype=np.uint64)
+    counters = np.zeros(2 * n_chain + npar, dtype=np.uint64)    # + chain 0's point after the last step, as doubles
     for layout, npc, skip, thin in ((0, 1, 0, 1), (0, n_chain, 2, 5), (0, 0, 36, 40), (0, 3, 0, 7), (1, 0, 0, 1), (1, 0, 4, 9), (1, 0, 37, 3)):
         kept = C.c_uint64(0)
         capi.check(L.apemost_hip_samples_pack_read_async(s._h, rows.data_ptr(), n_steps, skip, thin, npc, layout, packed.data_ptr(),
@@ -220,7 +220,9 @@ def test_samples_packed_on_the_device_equal_the_rows_repacked_on_the_host():
         got = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_double)), shape=(ref.size,))[:want.size]
         assert np.array_equal(got, want), (layout, npc, skip, thin)
         dev = s.get_state()
-        assert np.array_equal(counters[:n_chain], dev.accept) and np.array_equal(counters[n_chain:], dev.reject)
+        assert np.array_equal(counters[:n_chain], dev.accept) and np.array_equal(counters[n_chain:2 * n_chain], dev.reject)
+        # (what the C host's progress line prints: the kept steps may end earlier, or be none -- skip 37 of 37)
+        assert np.array_equal(counters[2 * n_chain:].view(np.float64), ref[-1, 0, :npar])
     assert L.apemost_hip_samples_pack_read_async(s._h, rows.data_ptr(), n_steps, 0, 0, 0, 0, packed.data_ptr(), host, None,
                                                  None) == capi.ERR_INVALID          # thin 0
     capi.check(L.apemost_hip_host_free(host))

@@ -16,7 +16,9 @@ export TMPDIR=/tmp
 # --no-torch: the profiled process holds one HIP / HSA runtime (with torch's bundled one beside the tool's, the
 # passes of config 4 -- cooperative launches -- aborted inside exit(), profiles/README.md); -e again since then
 set -e
-common="--config $cfg --cpu-seconds 0 --steps 4 --warmup 1 --no-torch $*"
+# (60 launches per bench step: a few hundred dispatches of the stepping kernel per pass keep the counter files small;
+# the driver's default is several hundred launches per step so that 20 steps are 5 s of GPU time)
+common="--config $cfg --cpu-seconds 0 --steps 4 --warmup 1 --launches-per-step 60 --no-torch $*"
 python3 bench.py $common > $out/bench_short.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $common > $out/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py $common > $out/fetch.log 2>&1

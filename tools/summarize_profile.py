@@ -97,7 +97,7 @@ def main():
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
     out = {"config": int(cfg), "tag": tag,
-           "command": "tools/profile_config.sh %s %s  (rocprofv3 ... -- python3 bench.py --config %s --cpu-seconds 0 --steps 4 --warmup 1 --no-torch)" % (cfg, tag, cfg)}
+           "command": "tools/profile_config.sh %s %s  (rocprofv3 ... -- python3 bench.py --config %s --cpu-seconds 0 --steps 4 --warmup 1 --launches-per-step 60 --no-torch)" % (cfg, tag, cfg)}
     try:
         out["bench_line"] = json.loads(open(os.path.join(src, "bench_short.json")).read().strip().splitlines()[-1])
     except (OSError, ValueError, IndexError):
