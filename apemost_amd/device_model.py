@@ -1,7 +1,7 @@
 """Compile check for a user-supplied device likelihood (include/apemost_device_model.h) without a GPU:
 the same translation unit the engine hands to hiprtc when a sampler of APEMOST_MODEL_USER is created
-(apemost_hip.hip user_model_build) -- '#include "pt_kernels.h"' + the user's file, the four one-wave
-kernels named as template instantiations -- compiled for gfx950 through libhiprtc with ctypes.
+(apemost_hip.hip user_model_build) -- '#include "pt_kernels.h"' + the user's file, the four kernels of
+each workgroup shape (1, 2, 4, 8 waves per chain) named as template instantiations -- compiled for gfx950 through libhiprtc with ctypes.
 
     python -m apemost_amd.device_model my_model.hip
 """
@@ -31,9 +31,13 @@ def compile_check(path, variant=False, arch="gfx950"):
     if rtc.hiprtcCreateProgram(C.byref(prog), src, b"apemost_user_model.hip", 0, None, None) != 0:
         raise RuntimeError("hiprtcCreateProgram failed")
     km = MODEL_USER + (VARIANT if variant else 0)
-    for name in ("apemost::pt_round_kernel<%d, 1, false, false>" % km, "apemost::pt_calibrate_kernel<%d, 1, false, false>" % km,
-                 "apemost::pt_calc_model_kernel<%d, 1, false>" % MODEL_USER, "apemost::pt_loglike_kernel<%d, 1, false>" % MODEL_USER):
-        rtc.hiprtcAddNameExpression(prog, name.encode())
+    for w in (1, 2, 4, 8):          # the workgroup shapes the engine instantiates (apemost_hip.hip kUserWaves)
+        prod = "true" if w >= 4 else "false"
+        for name in ("apemost::pt_round_kernel<%d, %d, false, %s>" % (km, w, prod),
+                     "apemost::pt_calibrate_kernel<%d, %d, false, %s>" % (km, w, prod),
+                     "apemost::pt_calc_model_kernel<%d, %d, false>" % (MODEL_USER, w),
+                     "apemost::pt_loglike_kernel<%d, %d, false>" % (MODEL_USER, w)):
+            rtc.hiprtcAddNameExpression(prog, name.encode())
     opts = [b"--offload-arch=" + arch.encode(), b"-O3", b"-ffp-contract=off", b"-std=c++17",
             b"-I" + os.path.join(HERE, "csrc").encode(), b"-I" + os.path.join(ROOT, "include").encode(), b"-I/opt/rocm/include"]
     rc = rtc.hiprtcCompileProgram(prog, len(opts), (C.c_char_p * len(opts))(*opts))
