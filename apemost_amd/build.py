@@ -19,6 +19,18 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _sources_sha1(paths):
+    import hashlib
+    h = hashlib.sha1()
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+LAST_BUILD = {"compiled": [], "linked": False}   # what the last build_hip() call did (reported by __graft_entry__.build)
+
+
 OBJ = os.path.join(CSRC, "obj")
 MODEL_TUS = (0, 1, 2, 3, 8, 9, 10, 11)   # the built-in models and their variant instantiations (pt_device.h kVariantModel)
 
@@ -36,6 +48,14 @@ def build_hip(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     abi_src, model_src, headers = _sources()
     os.makedirs(OBJ, exist_ok=True)
+    # The objects and the library travel with a snapshot of the tree (gpurun), where file times need not mean
+    # what they meant here: the hash of the sources the library was built from is kept beside it, and a library
+    # whose stamp differs from the sources present is rebuilt whatever the file times say.
+    stamp = HIP_LIB + ".sources_sha1"
+    want = _sources_sha1([abi_src, model_src] + headers)
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if have != want and os.path.exists(HIP_LIB):
+        force = True
     compile_flags = [f for f in HIP_FLAGS if f != "-shared"] + ["-c", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     jobs = []
     abi_obj = os.path.join(OBJ, "abi.o")
@@ -57,8 +77,13 @@ def build_hip(force=False, verbose=False):
         workers = max(1, min(len(jobs), os.cpu_count() or 1, int(os.environ.get("APEMOST_BUILD_JOBS", "8"))))
         with ThreadPoolExecutor(workers) as pool:
             list(pool.map(run, jobs))
-    if jobs or force or _stale(HIP_LIB, objs):
+    link = bool(jobs) or force or _stale(HIP_LIB, objs)
+    if link:
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"])
+    if link or have != want:
+        open(stamp, "w").write(want + "\n")
+    LAST_BUILD["compiled"] = [os.path.basename(j[j.index("-o") + 1]) for j in jobs]
+    LAST_BUILD["linked"] = link
     return HIP_LIB
 
 
