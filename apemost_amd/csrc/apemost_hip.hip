@@ -750,7 +750,8 @@ static int create_body(apemost_hip_sampler *s) {
         }
         s->resident_ok = s->resident_lds || s->resident_plain;
         s->cooperative = (cfg->flags & APEMOST_HIP_FLAG_COOPERATIVE_LAUNCH) && prop.cooperativeLaunch && !s->user.module;
-        if (!s->resident_ok && prop.cooperativeLaunch && s->one_barrier) {
+        // (APEMOST_COOP_ANY=1: the same for the two-phase kernels -- an experiment switch, tools/experiments/r04_session6.sh)
+        if (!s->resident_ok && prop.cooperativeLaunch && (s->one_barrier || getenv("APEMOST_COOP_ANY")) && !s->user.module) {
             // (the one-barrier kernels only: their steps take a microsecond and a launch per round
             // costs a multiple of that; 2048 one-wave chains of config 5 would fit too, but a round
             // there is a 340 us launch and the in-launch hand-off was measured 3 % behind)

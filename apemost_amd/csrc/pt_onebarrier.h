@@ -120,6 +120,9 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
     } while (0)
 #endif
 
+#ifndef APEMOST_OB_WAVE_PERM
+#define APEMOST_OB_WAVE_PERM 0
+#endif
 // APEMOST_OB_HELPER_WAVE: the helper of the kSplit models as a ninth (LW + 5th) wavefront of the workgroup instead
 // of a duty of the candidate producers
 #ifndef APEMOST_OB_HELPER_WAVE
@@ -205,6 +208,13 @@ struct ObEngine {
     __device__ __forceinline__ void setup_common(const DevArrays &d, const ChainShape &sh, int c, double *lds_) {
         lane = threadIdx.x & (kWave - 1);
         hw = threadIdx.x / kWave;
+#if APEMOST_OB_WAVE_PERM
+        // (experiment, round 4) which role a hardware wave takes, i.e. which roles share a SIMD (wave w runs on
+        // SIMD w mod 4): 1 = owner + a producer on SIMD 0, two likelihood waves on SIMD 1; 2 = owner + producer,
+        // likelihood waves in two pairs, two producers together.  One nibble per hardware wave, LW = 4 only.
+        if (LW == 4 && !kHelperWave)
+            hw = (int)(((APEMOST_OB_WAVE_PERM == 1 ? 0x76352104u : 0x73256104u) >> (4 * hw)) & 0xFu);
+#endif
         wave = hw == LW ? 0 : hw + 1;
         tid = hw * kWave + lane;
         n_par = sh.n_par;

@@ -4,6 +4,11 @@
  * TEST INFRASTRUCTURE ONLY (see apemost_oracle.h).  Plain C, libm, optional
  * OpenMP for the timed CPU baseline.  Written from the behaviour of the
  * reference (file:line cited per function), not copied from it.
+ *
+ * Pinning: the mt19937 and Philox streams, the manual's eval example, the reference's parser fixtures and the
+ * survey's recorded config-1 counters are reproduced (tests/test_oracle_pins.py, test_oracle_workflow.py).
+ * PARITY UNPINNED by reference-held fixtures for sampler trajectories, swaps, calibration and the pulse
+ * likelihoods: the reference holds none and cannot be built here (no GSL); DESIGN.md 2.
  */
 #include "apemost_oracle.h"
 

@@ -6,7 +6,10 @@ set -o pipefail
 suffix=${1:-a}
 for cfg in ${2:-2 3 4 5}; do
   extra=""
-  [ $cfg = 5 ] && extra="--burn-in 100"
+  # (config 5's shard -- 2048 one-wave workgroups, eight per CU: the occupancy figure itself, one more than the
+  # residency estimate admits -- steps one round per launch: a bench "launch" of 32 rounds is 32 dispatches there, and
+  # every dispatch under --pmc costs ~0.1 s of counter read-back: 3 batches per step, not 60)
+  [ $cfg = 5 ] && extra="--burn-in 100 --launches-per-step 3"
   tools/profile_config.sh $cfg r04_c${cfg}_$suffix $extra || echo "config $cfg profile failed"
 done
 echo profiles done
