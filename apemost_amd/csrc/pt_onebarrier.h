@@ -494,12 +494,18 @@ struct ObEngine {
         if constexpr (Model<kBase>::kLogProduct) {
             acc += lp.template finish<false>(m.tab);
             // rare: a pair product next to the subnormals or a sum that is not finite -- the wave takes its
-            // share again in the reference's operation order (LogProdT, Model::term_ref)
-            if (__ballot(lp.bad(acc)) != 0) {
+            // share again in the reference's operation order (LogProdT, Model::term_ref).  The test sits BEHIND
+            // the cross-lane sum of the fast form: the ballot and its branch are then off the step's dependent
+            // chain (the branch is decided while the six DPP stages run) instead of in front of it.
+            const u64 suspect = __ballot(lp.bad(acc));
+            double total = wave_reduce_sum_lane63(acc);
+            if (suspect != 0) {
                 acc = 0;
                 for (int k = tid; k < n_data; k += kLikThreads)
                     acc += m.term_ref(xs[k], ys[k]);
+                total = wave_reduce_sum_lane63(acc);
             }
+            return total; // valid in lane 63
         }
         return wave_reduce_sum_lane63(acc); // valid in lane 63
     }
