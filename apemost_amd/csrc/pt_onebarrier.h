@@ -123,6 +123,9 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
 #ifndef APEMOST_OB_WAVE_PERM
 #define APEMOST_OB_WAVE_PERM 0
 #endif
+#ifndef APEMOST_OB_SKIP_LOOPS
+#define APEMOST_OB_SKIP_LOOPS 0
+#endif
 // APEMOST_OB_HELPER_WAVE: the helper of the kSplit models as a ninth (LW + 5th) wavefront of the workgroup instead
 // of a duty of the candidate producers
 #ifndef APEMOST_OB_HELPER_WAVE
@@ -465,6 +468,11 @@ struct ObEngine {
             add_terms<kWide, kShortChain, false>(m, row_x, row_y, acc, lp);
             i = n_data;
         }
+#if APEMOST_OB_SKIP_LOOPS
+        // (experiment, round 4) the whole vector is in registers: not three loop tests that all fail, one
+        if (!rows_in_regs)
+#endif
+        {
         if (LW < 8) {
             for (; i + 3 * kLikThreads < n_data; i += 4 * kLikThreads) {
                 const double x4[4] = {xs[i], xs[i + kLikThreads], xs[i + 2 * kLikThreads], xs[i + 3 * kLikThreads]};
@@ -490,6 +498,7 @@ struct ObEngine {
                 add_terms<1, kShortChain, false>(m, x1, y1, acc, lp);
             else
                 acc += m.term(xs[i], ys[i]);
+        }
         }
         if constexpr (Model<kBase>::kLogProduct) {
             acc += lp.template finish<false>(m.tab);

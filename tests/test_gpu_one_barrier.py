@@ -202,3 +202,33 @@ def test_injected_ties_of_the_accept_comparison(name, capsys):
         assert ob_c[0] and not ob_c[-1], c
         differ = np.array(ks)[ref_c != ob_c]
         assert np.all(np.abs(differ) <= kWindow), (c, differ)
+
+
+@pytest.mark.parametrize("name,sf,sh", [("pulse", 1e30, 1e200), ("pulse_vrot", 1e30, 1e-200), ("pulse", 1.0, 1e-250)])
+def test_one_barrier_sampling_through_the_range_guard_matches_oracle(name, sf, sh):
+    """The pulse likelihoods' pair-range guard inside the one-barrier step: a spectrum in units where the products of
+    two points' numerators or denominators leave fp64's range (frequencies x sf with the lifetime / sf, heights and data x
+    sh), so that every evaluation of every likelihood wave falls back to the reference's operation order
+    (ObEngine::lik_partial -> Model::term_ref) -- sampled with swaps against the oracle: counters and ticks exact, rows
+    1e-9, and bit-identical to the two-phase kernel (whose Engine::lane_sum takes the same fallback)."""
+    w = small_workloads()[name]
+    heights = [3, 5] if name == "pulse" else [4, 6]
+    freqs = [2, 4] if name == "pulse" else [2, 3, 5]
+    w.data = w.data.copy()
+    w.data[:, 0] *= sf
+    w.data[:, 1] *= sh
+    for a in (w.start, w.pmin, w.pmax, w.step):
+        a[0] /= sf
+        a[freqs] *= sf
+        a[heights] *= sh
+    n_chain, n_rounds, n_swap, seed = 6, 25, 7, 83
+    st, lad, rng = make_pair(w, n_chain, seed=seed)
+    a, sa = _run(w, st, n_chain, n_rounds, n_swap, 4, seed)
+    b, sb = _run(w, st, n_chain, n_rounds, n_swap, 4, seed, flags=capi.FLAG_TWO_BARRIER_STEP)
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert np.array_equal(sa, sb)
+    ref = orc.run_sampler(lad, rng, n_rounds, n_swap, record=True)
+    assert_match(a, lad, rng, what="range guard " + name)
+    np.testing.assert_allclose(sa, ref, rtol=1e-9, atol=0)
+    assert np.all(np.isfinite(sa)) and 0 < a.accept.sum() < a.n_iter.sum()
