@@ -123,8 +123,15 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
 #ifndef APEMOST_OB_WAVE_PERM
 #define APEMOST_OB_WAVE_PERM 0
 #endif
+// The likelihood waves' step, read in the code object (round 4, profiles/r04_lik_step_microfixes.txt): measured on, kept on.
 #ifndef APEMOST_OB_SKIP_LOOPS
-#define APEMOST_OB_SKIP_LOOPS 0
+#define APEMOST_OB_SKIP_LOOPS 1
+#endif
+#ifndef APEMOST_OB_PART_FIRST
+#define APEMOST_OB_PART_FIRST 1
+#endif
+#ifndef APEMOST_OB_FLAG_LATE
+#define APEMOST_OB_FLAG_LATE 0
 #endif
 // APEMOST_OB_HELPER_WAVE: the helper of the kSplit models as a ninth (LW + 5th) wavefront of the workgroup instead
 // of a duty of the candidate producers
@@ -469,7 +476,9 @@ struct ObEngine {
             i = n_data;
         }
 #if APEMOST_OB_SKIP_LOOPS
-        // (experiment, round 4) the whole vector is in registers: not three loop tests that all fail, one
+        // The whole vector is one pass held in registers (configs 2 and 4): all three loops below are empty -- but each
+        // loop test is per lane (v_cmp -> s_and_saveexec -> s_cbranch_execz -> s_or exec) and sat on the step's dependent
+        // chain; ONE uniform test in front of them: config 2 2.078 -> 2.141e8 steps/s (+3 %), config 4 +0.8 %.
         if (!rows_in_regs)
 #endif
         {
@@ -530,24 +539,46 @@ struct ObEngine {
 #pragma unroll
         for (int w = 0; w < LW; w++)
             part[w] = sp[w];
+#if APEMOST_OB_PART_FIRST
+        // The partial sums FIRST in the LDS queue: the add tree is the head of the step's chain, the proposal rows are
+        // not needed before the select behind it (left to itself the compiler requests the threshold, the flag and the
+        // four row reads ahead of them).  Worth nothing by itself beyond the skipped loops; kept with mov_dpp, with
+        // which it is the fastest combination measured (2.141 / 2.394e8 at configs 2 / 4).
+        asm volatile("" ::: "memory");
+#endif
         double limit = *s_thr(parity);
         if constexpr (kSplit)
             limit = ObThreshold<kBase>::limit(*s_thx(parity), limit); // (one subtraction beside the partial sums' tree)
         const int pending = *s_flag(parity);
         m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
+#if !APEMOST_OB_FLAG_LATE
         if (__builtin_amdgcn_readfirstlane(pending) != 0) {
             // rare: the owner is replacing a proposal that could not be prepared (redraw path);
             // every wave of the workgroup takes this barrier, then the rows are read again
             __syncthreads();
             m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
         }
+#endif
 #pragma unroll
         for (int span = 1; span < LW; span *= 2) {
 #pragma unroll
             for (int w = 0; w + span < LW; w += 2 * span)
                 part[w] += part[w + span];
         }
+#if APEMOST_OB_FLAG_LATE
+        // (measured and not taken, round 4: 2.06-2.14e8 at config 2 depending on what else is switched on, never above the
+        // combinations without it) the redraw flag's test BEHIND the add tree: the decision needs the partial sums
+        // and the threshold only, and a branch in front of the tree holds the wave until the flag has come back
+        const bool first = part[0] < limit;
+        asm volatile("" : "+v"(part[0]));
+        if (__builtin_amdgcn_readfirstlane(pending) != 0) {
+            __syncthreads();
+            m.fetch2(s_prop(parity, 0), s_prop(parity, 1));
+        }
+        m.pick2(first, n_par);
+#else
         m.pick2(part[0] < limit, n_par);
+#endif
         const double mine = lik_partial();
         if (lane == 63)
             s_part(parity ^ 1)[hw] = mine;
