@@ -8,7 +8,8 @@ mkdir -p gpurun_out/r04_final
 ( while sleep 45; do date >> gpurun_out/r04_final/heartbeat.txt; done ) &
 hb=$!
 trap "kill $hb" EXIT
-for cfg in ${3:-2 3 4 5}; do
+benches="${3:-2 3 4 5}"; [ "$benches" = "-" ] && benches=""
+for cfg in $benches; do
   extra=""
   [ $cfg = 5 ] && extra="--burn-in 100"
   timeout -k 10 400 python bench.py --config $cfg $extra > gpurun_out/r04_final/bench_c$cfg.json 2> gpurun_out/r04_final/bench_c$cfg.err \
