@@ -315,6 +315,8 @@ struct apemost_hip_sampler {
     hipEvent_t ev_copy;
     u64 *h_word;             // pinned copy of the launch error word, refreshed by every async read
     bool one_barrier;    // stepping launches use pt_round_ob_kernel
+    bool ob_helper;      // ... in its form with a helper wavefront (see ob_wants_helper)
+    int cus;             // compute units of the device
     int kmodel;          // template argument of this sampler's kernels: cfg.model, + kVariantModel when a
                          // non-default proposal law or swap schedule is asked for (pt_device.h)
     bool cooperative;    // multi-round launches through hipLaunchCooperativeKernel
@@ -368,8 +370,9 @@ static int enable_big_lds(apemost_hip_sampler *s, int waves);
 static int max_rounds_per_launch(apemost_hip_sampler *s);
 static int user_model_build(apemost_hip_sampler *s);
 template <bool LDS>
-static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks);
+static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, bool helper, size_t lds_bytes, int *blocks);
 static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data);
+static bool ob_wants_helper(const apemost_hip_sampler *s, int n_chains);
 
 template <class T>
 static int dev_alloc(apemost_hip_sampler *s, T **p, size_t count) {
@@ -731,19 +734,28 @@ static int create_body(apemost_hip_sampler *s) {
         // the round kernel this sampler's stepping launches use: one barrier per step where that
         // variant exists (8 likelihood waves per chain), the classic two-phase step otherwise
         s->one_barrier = has_one_barrier(s->waves) && !(cfg->flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP) && !s->user.module;
+        s->cus = prop.multiProcessorCount;
+        s->ob_helper = s->one_barrier && ob_wants_helper(s, cfg->n_chains);
         int b_lds = 0, b_plain = 0;
         if (s->user.module) {
             HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&b_plain, s->user.round[s->waves], s->waves * kWave, s->lds_fixed_bytes));
         } else {
         if (s->lds_data)
-            HIP_TRY(round_occupancy<true>(s->kmodel, s->waves, s->producers, s->one_barrier,
+            HIP_TRY(round_occupancy<true>(s->kmodel, s->waves, s->producers, s->one_barrier, s->ob_helper,
                                           s->one_barrier ? ob_lds_bytes(s, true) : s->lds_bytes, &b_lds));
-        HIP_TRY(round_occupancy<false>(s->kmodel, s->waves, s->producers, s->one_barrier,
+        HIP_TRY(round_occupancy<false>(s->kmodel, s->waves, s->producers, s->one_barrier, s->ob_helper,
                                        s->one_barrier ? ob_lds_bytes(s, false) : s->lds_fixed_bytes, &b_plain));
         }
         const long long cus = prop.multiProcessorCount;
         s->resident_lds = s->lds_data && (long long)cfg->n_chains <= (long long)(b_lds - 1) * cus;
         s->resident_plain = (long long)cfg->n_chains <= (long long)(b_plain - 1) * cus;
+        if (s->ob_helper) {
+            // Workgroups with a helper wavefront are chosen for ladders of at most one chain per CU (ob_wants_helper)
+            // and a CU admits one of them or two: a kernel that launches at all has a workgroup per CU resident,
+            // whatever the occupancy query's last block is worth.
+            s->resident_lds = s->lds_data && b_lds >= 1;
+            s->resident_plain = b_plain >= 1;
+        }
         if ((long long)cfg->n_chains * 2 <= cus) { // at most one workgroup per two CUs
             s->resident_lds = s->lds_data;
             s->resident_plain = true;
@@ -949,7 +961,7 @@ extern "C" int apemost_hip_launch_policy(apemost_hip_sampler *s, int32_t *one_ba
                                          int32_t *max_rounds) {
     CHECK_S(s);
     if (one_barrier)
-        *one_barrier = s->one_barrier ? 1 : 0;
+        *one_barrier = s->one_barrier ? (s->ob_helper ? 2 : 1) : 0;
     if (cooperative)
         *cooperative = (s->cooperative && s->resident_ok && !s->handoff_failed) ? 1 : 0;
     if (max_rounds)
@@ -1080,6 +1092,18 @@ extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, in
     return APEMOST_HIP_OK;
 }
 
+// The one-barrier step with a helper wavefront (pt_onebarrier.h, HELPER): the models with a prior, where every
+// workgroup of the launch has a CU to itself -- nine (thirteen) wavefronts; two such workgroups on a CU were not
+// measured to gain (ladders of 257-512 chains keep the eight-wave form and its two workgroups per CU).
+// APEMOST_OB_HELPER=0/1 overrides the choice (A/B runs, tests).
+static bool ob_wants_helper(const apemost_hip_sampler *s, int n_chains) {
+    if (!ob_can_help(s->kmodel))
+        return false;
+    if (const char *env = getenv("APEMOST_OB_HELPER"))
+        return atoi(env) != 0;
+    return n_chains <= s->cus;
+}
+
 static size_t ob_lds_bytes(const apemost_hip_sampler *s, bool lds_data) {
     return (size_t)kObFixedDoubles * sizeof(double) + (lds_data ? (size_t)2 * s->cfg.n_data * sizeof(double) : 0);
 }
@@ -1092,11 +1116,12 @@ static size_t classic_lds_bytes(const apemost_hip_sampler *s, int waves, bool ld
 // one launch with an explicit workgroup shape (the stepping launches use the sampler's own; the
 // calibration picks one per segment, by the number of chains that are still calibrating)
 static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, int waves, bool lds_data,
-                        bool coop) {
+                        bool coop, bool helper = false) {
     LaunchOp op;
     op.kind = kind;
     op.lds_data = lds_data;
     op.producers = has_producer(waves);
+    op.helper = helper;
     op.coop = coop;
     op.grid = grid;
     op.lds = (kind == K_ROUND_OB || kind == K_CALIB_OB) ? ob_lds_bytes(s, lds_data) : classic_lds_bytes(s, waves, lds_data);
@@ -1128,7 +1153,7 @@ static int launch_shape(apemost_hip_sampler *s, KernelKind kind, int grid, const
 // likelihood evaluations) reads it through L2 instead of copying it into LDS first
 static int launch(apemost_hip_sampler *s, KernelKind kind, int grid, const void *args, bool stage_data = true,
                   bool coop = false) {
-    return launch_shape(s, kind, grid, args, s->waves, s->lds_data && stage_data, coop);
+    return launch_shape(s, kind, grid, args, s->waves, s->lds_data && stage_data, coop, kind == K_ROUND_OB && s->ob_helper);
 }
 
 extern "C" int apemost_hip_calc_model(apemost_hip_sampler *s, int32_t first, int32_t count) {
@@ -1193,10 +1218,11 @@ extern "C" int apemost_hip_loglike(apemost_hip_sampler *s, int32_t n, const doub
 }
 
 template <bool LDS>
-static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, size_t lds_bytes, int *blocks) {
+static hipError_t round_occupancy(int model, int waves, bool producers, bool one_barrier, bool helper, size_t lds_bytes, int *blocks) {
     OccupancyOp<LDS> op;
     op.producers = producers;
     op.one_barrier = one_barrier;
+    op.helper = helper;
     op.lds_bytes = lds_bytes;
     op.blocks = blocks;
     return dispatch(model, waves, op);
@@ -1698,7 +1724,7 @@ extern "C" void apemost_hip_calib_defaults(apemost_hip_calib_config *c) {
 // as are still calibrating (a forced waves_per_chain stays forced)
 struct CalibShape {
     int waves;
-    bool lds_data, one_barrier;
+    bool lds_data, one_barrier, helper;
     u64 budget;
 };
 
@@ -1711,12 +1737,13 @@ static CalibShape calib_shape(const apemost_hip_sampler *s, int n_active) {
         g.waves = s->waves; // (development builds hold only some shapes)
     g.one_barrier = has_one_barrier(g.waves) && s->kmodel < kVariantModel && !(s->cfg.flags & APEMOST_HIP_FLAG_TWO_BARRIER_STEP) &&
                     !s->user.module;
+    g.helper = g.one_barrier && ob_wants_helper(s, n_active);
     const size_t bytes = g.one_barrier ? ob_lds_bytes(s, true) : classic_lds_bytes(s, g.waves, true);
     g.lds_data = !s->user.module && bytes <= 160 * 1024 - 1024 && c.lds_policy != 2 && (c.lds_policy == 1 || choose_lds(c, bytes));
     // A segment of about a quarter of a second: likelihood evaluations a chain gets through in that
     // time, from a coarse model of one evaluation (1.7 ns per data point and wavefront, 0.7 us at
     // least, stretched when the wavefronts outnumber the SIMDs).  Always whole blocks, at least one.
-    const double waves_per_wg = g.one_barrier ? g.waves + 4 : g.waves;
+    const double waves_per_wg = g.one_barrier ? g.waves + 4 + (g.helper ? 1 : 0) : g.waves;
     double t_eval = 1.7e-9 * s->cfg.n_data / g.waves;
     if (t_eval < 0.7e-6)
         t_eval = 0.7e-6;
@@ -1757,7 +1784,7 @@ static int calib_launch_segment(apemost_hip_sampler *s) {
     a.progress = k.d_progress;
     a.progress_cap = k.progress_cap;
     a.budget = g.budget;
-    rc = launch_shape(s, g.one_barrier ? K_CALIB_OB : K_CALIB, k.n_active, &a, g.waves, g.lds_data, false);
+    rc = launch_shape(s, g.one_barrier ? K_CALIB_OB : K_CALIB, k.n_active, &a, g.waves, g.lds_data, false, g.helper);
     if (rc)
         return rc;
     HIP_TRY(hipMemcpyAsync(k.h_rec, k.d_rec, (size_t)k.count * sizeof(CalibRec), hipMemcpyDeviceToHost, s->stream));

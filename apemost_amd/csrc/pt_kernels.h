@@ -445,10 +445,10 @@ __device__ __forceinline__ u64 rounds_restarting(const E &e, const RoundArgs &a,
     return __ballot(involved) | (base == 0 ? 1ull : 0ull);
 }
 
-template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_round_ob_kernel(const RoundArgs a) {
+template <int MODEL, int LW, bool LDS_DATA, bool HELPER>
+__global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_round_ob_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
-    ObEngine<MODEL, LW, LDS_DATA> e;
+    ObEngine<MODEL, LW, LDS_DATA, HELPER> e;
     const int c = blockIdx.x;
     e.setup_common(a.d, a.sh, c, lds);
     OB_STAMP_DECL;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_pe
         }
         OB_STAMP_FLUSH;
     } else if (e.is_helper()) {
-        // (APEMOST_OB_HELPER_WAVE) the helper alone: the barrier sequence of a producer, helper_step per step
+        // (HELPER) the helper alone: the barrier sequence of a producer, helper_step per step
         if constexpr (decltype(e)::kHelperWave) {
             e.setup_lanes(a.sh, c);
             e.setup_helper(a.d, a.sh, c);
@@ -998,10 +998,10 @@ void pt_calibrate_kernel(const CalibArgs a) {
 // sweeps only the owner's work changes (attempts(which)): the likelihood waves see two prepared
 // parameter vectors as ever.  The proposal of parameter p+1 does not depend on the outcome of
 // parameter p's step, only the rest of the vector does, so both variants carry the same attempt.
-template <int MODEL, int LW, bool LDS_DATA>
-__global__ __launch_bounds__(ob_block(MODEL, LW)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_calibrate_ob_kernel(const CalibArgs a) {
+template <int MODEL, int LW, bool LDS_DATA, bool HELPER>
+__global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_calibrate_ob_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
-    ObEngine<MODEL, LW, LDS_DATA> e;
+    ObEngine<MODEL, LW, LDS_DATA, HELPER> e;
     const int slot = a.list[blockIdx.x];
     const int c = a.first + slot;
     e.setup_common(a.d, a.sh, c, lds);
@@ -1213,8 +1213,29 @@ namespace apemost {
 // ---- launch dispatch over (model, waves, lds) ----
 enum KernelKind { K_ROUND, K_ROUND_OB, K_CALC, K_EVAL, K_CALIB, K_CALIB_OB };
 
+// the one-barrier kernels of one (model, waves, staging, helper) shape
+template <int MODEL, int WAVES, bool LDS, bool HELPER>
+static hipError_t launch_ob(KernelKind kind, bool coop, int grid, size_t lds, hipStream_t st, const void *args) {
+    const dim3 g(grid), bo(ob_block(WAVES, HELPER)); // likelihood waves + owner + three candidate producers (+ helper)
+    if (kind == K_ROUND_OB) {
+        if (coop) {
+            void *params[] = {const_cast<void *>(args)};
+            return hipLaunchCooperativeKernel((const void *)pt_round_ob_kernel<MODEL, WAVES, LDS, HELPER>, g, bo, params,
+                                              (unsigned int)lds, st);
+        }
+        hipLaunchKernelGGL((pt_round_ob_kernel<MODEL, WAVES, LDS, HELPER>), g, bo, lds, st, *(const RoundArgs *)args);
+    } else {
+        // (the default proposal law and swap schedule only: the variants calibrate on the two-phase step)
+        if constexpr (MODEL < kVariantModel)
+            hipLaunchKernelGGL((pt_calibrate_ob_kernel<MODEL, WAVES, LDS, HELPER>), g, bo, lds, st, *(const CalibArgs *)args);
+        else
+            return hipErrorInvalidDeviceFunction;
+    }
+    return hipGetLastError();
+}
+
 template <int MODEL, int WAVES, bool LDS>
-static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int grid, size_t lds, hipStream_t st,
+static hipError_t launch_one(KernelKind kind, bool producers, bool helper, bool coop, int grid, size_t lds, hipStream_t st,
                              const void *args) {
     const dim3 g(grid), b(WAVES * kWave);
     constexpr bool kCanProduce = has_producer(WAVES);
@@ -1232,18 +1253,18 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
         hipLaunchKernelGGL((pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st, *(const RoundArgs *)args);
         break;
     case K_ROUND_OB:
+    case K_CALIB_OB:
         if constexpr (has_one_barrier(WAVES)) {
-            const dim3 bo(ob_block(MODEL, WAVES)); // + owner + three candidate producers (+ helper)
-            if (coop) {
-                void *params[] = {const_cast<void *>(args)};
-                return hipLaunchCooperativeKernel((const void *)pt_round_ob_kernel<MODEL, WAVES, LDS>, g, bo, params,
-                                                  (unsigned int)lds, st);
+            if constexpr (ob_can_help(MODEL)) {
+                if (helper)
+                    return launch_ob<MODEL, WAVES, LDS, true>(kind, coop, grid, lds, st, args);
             }
-            hipLaunchKernelGGL((pt_round_ob_kernel<MODEL, WAVES, LDS>), g, bo, lds, st, *(const RoundArgs *)args);
+            if (helper)
+                return hipErrorInvalidDeviceFunction;
+            return launch_ob<MODEL, WAVES, LDS, false>(kind, coop, grid, lds, st, args);
         } else {
             return hipErrorInvalidDeviceFunction;
         }
-        break;
     case K_CALC:
         hipLaunchKernelGGL((pt_calc_model_kernel<MODEL % kVariantModel, WAVES, LDS>), g, b, lds, st,
                            *(const RoundArgs *)args);
@@ -1254,15 +1275,6 @@ static hipError_t launch_one(KernelKind kind, bool producers, bool coop, int gri
     case K_CALIB:
         hipLaunchKernelGGL((pt_calibrate_kernel<MODEL, WAVES, LDS, kCanProduce>), g, bp, lds, st,
                            *(const CalibArgs *)args);
-        break;
-    case K_CALIB_OB:
-        // (the default proposal law and swap schedule only: the variants calibrate on the two-phase step)
-        if constexpr (has_one_barrier(WAVES) && MODEL < kVariantModel) {
-            const dim3 bo(ob_block(MODEL, WAVES));
-            hipLaunchKernelGGL((pt_calibrate_ob_kernel<MODEL, WAVES, LDS>), g, bo, lds, st, *(const CalibArgs *)args);
-        } else {
-            return hipErrorInvalidDeviceFunction;
-        }
         break;
     }
     return hipGetLastError();
@@ -1318,19 +1330,31 @@ static hipError_t dispatch_w(int waves, const F &f) {
 
 struct LaunchOp {
     KernelKind kind;
-    bool lds_data, producers, coop;
+    bool lds_data, producers, helper, coop;
     int grid;
     size_t lds;
     hipStream_t st;
     const void *args;
     template <int MODEL, int WAVES>
     hipError_t run() const {
-        return lds_data ? launch_one<MODEL, WAVES, true>(kind, producers, coop, grid, lds, st, args)
-                        : launch_one<MODEL, WAVES, false>(kind, producers, coop, grid, lds, st, args);
+        return lds_data ? launch_one<MODEL, WAVES, true>(kind, producers, helper, coop, grid, lds, st, args)
+                        : launch_one<MODEL, WAVES, false>(kind, producers, helper, coop, grid, lds, st, args);
     }
 };
 
 // kernels that stage > 64 KiB of data in LDS must opt in once per function
+template <int MODEL, int WAVES, bool HELPER>
+static hipError_t set_ob_lds_attr(size_t ob_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void *)pt_round_ob_kernel<MODEL, WAVES, true, HELPER>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ob_bytes);
+    if (e != hipSuccess)
+        return e;
+    if constexpr (MODEL < kVariantModel)
+        e = hipFuncSetAttribute((const void *)pt_calibrate_ob_kernel<MODEL, WAVES, true, HELPER>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ob_bytes);
+    return e;
+}
+
 template <int MODEL, int WAVES>
 static hipError_t set_lds_attr(size_t bytes, size_t ob_bytes) {
     hipError_t e;
@@ -1351,13 +1375,11 @@ static hipError_t set_lds_attr(size_t bytes, size_t ob_bytes) {
     if (e != hipSuccess)
         return e;
     if constexpr (has_one_barrier(WAVES)) {
-        e = hipFuncSetAttribute((const void *)pt_round_ob_kernel<MODEL, WAVES, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ob_bytes);
+        e = set_ob_lds_attr<MODEL, WAVES, false>(ob_bytes);
         if (e != hipSuccess)
             return e;
-        if constexpr (MODEL < kVariantModel) {
-            e = hipFuncSetAttribute((const void *)pt_calibrate_ob_kernel<MODEL, WAVES, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ob_bytes);
+        if constexpr (ob_can_help(MODEL)) {
+            e = set_ob_lds_attr<MODEL, WAVES, true>(ob_bytes);
             if (e != hipSuccess)
                 return e;
         }
@@ -1377,16 +1399,21 @@ struct LdsAttrOp {
 template <bool LDS>
 struct OccupancyOp {
     bool producers;
-    bool one_barrier;
+    bool one_barrier, helper;
     size_t lds_bytes;
     int *blocks;
     template <int MODEL, int WAVES>
     hipError_t run() const {
         constexpr bool kCanProduce = has_producer(WAVES);
         if constexpr (has_one_barrier(WAVES)) {
+            if constexpr (ob_can_help(MODEL)) {
+                if (one_barrier && helper)
+                    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS, true>,
+                                                                        ob_block(WAVES, true), lds_bytes);
+            }
             if (one_barrier)
-                return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS>,
-                                                                    ob_block(MODEL, WAVES), lds_bytes);
+                return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_ob_kernel<MODEL, WAVES, LDS, false>,
+                                                                    ob_block(WAVES, false), lds_bytes);
         }
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, pt_round_kernel<MODEL, WAVES, LDS, kCanProduce>,
                                                             block_threads(WAVES, kCanProduce), lds_bytes);

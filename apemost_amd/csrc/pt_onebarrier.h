@@ -62,7 +62,6 @@ struct ObThreshold;
 // and the decision every wave makes anyway do not say (round 4).
 template <>
 struct ObThreshold<APEMOST_MODEL_SIMPLESIN> {
-    static constexpr bool kSplit = false;
     double denom_over_beta; // (-2 sigma^2) / beta < 0
     __device__ __forceinline__ void init(const ModelConsts &c, double beta) {
         denom_over_beta = (-2 * c.sigma * c.sigma) / beta;
@@ -77,24 +76,20 @@ struct ObThreshold<APEMOST_MODEL_SIMPLESIN> {
 template <>
 struct ObThreshold<APEMOST_MODEL_SINE3> : ObThreshold<APEMOST_MODEL_SIMPLESIN> {};
 
-// APEMOST_OB_SPLIT = 1 (measured in round 4 and NOT the default, profiles/r04_ob_helper_roles.txt): the prior of the
-// proposal in flight leaves the owner.  On the MI355X box config 4's shard runs 2.30e8 steps/s with the owner
-// computing it (0), 2.14 / 2.16e8 with a candidate producer as helper (decision first / both rows side by
-// side: that producer's Philox step becomes the longest wave of the workgroup, ~2100 of 2140 ticks), 2.28e8 with a
-// ninth wavefront as helper (APEMOST_OB_HELPER_WAVE; the grid then needs a cooperative launch at 256 chains).
-// The owner was not what the step waits for: the likelihood wave that shares the owner's SIMD is (1920-1990
-// ticks busy in every variant against 1650-1720 for its three siblings).
-#ifndef APEMOST_OB_SPLIT
-#define APEMOST_OB_SPLIT 0
-#endif
+// The models with a prior run with a HELPER wavefront where a workgroup has a CU to itself (ObEngine's HELPER
+// argument, chosen by the host): S_max = X - Y, the proposal's half X from the helper, the chain's half Y from the
+// owner.  History (profiles/r04_ob_helper_roles.txt, r04_pulse_helper_wave.txt): with the prior on the owner config 4's
+// shard ran 2.30e8 steps/s and a helper changed nothing (2.28e8) while the likelihood waves' step still carried the
+// guard's branch and three empty per-lane loops; with those gone (2.39e8) the owner is what the step waits for, and
+// the ninth wavefront gives 2.48e8 and a calibration of 0.33 instead of 0.40 s.  A candidate producer as helper (its
+// Philox step becomes the longest wave of the workgroup: 2.14-2.16e8) is not an option and no longer in the source.
 template <>
 struct ObThreshold<APEMOST_MODEL_PULSE> {
-    static constexpr bool kSplit = APEMOST_OB_SPLIT != 0;
     double inv_beta;
     __device__ __forceinline__ void init(const ModelConsts &, double beta) { inv_beta = 1.0 / beta; }
     // prob_new = prior + -beta (p1 + S) > T  <=>  S < (prior - T) / beta - p1 = (prior / beta - p1) - T / beta
     template <class M>
-    __device__ __forceinline__ double s_max(double T, const M &, double prior_new, double p1) const { // (!kSplit: the owner alone)
+    __device__ __forceinline__ double s_max(double T, const M &, double prior_new, double p1) const { // (no helper: the owner alone)
         return (prior_new - T) * inv_beta - p1;
     }
     __device__ __forceinline__ double x_part(double prior_new, double p1) const { return prior_new * inv_beta - p1; }
@@ -133,18 +128,15 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
 #ifndef APEMOST_OB_FLAG_LATE
 #define APEMOST_OB_FLAG_LATE 0
 #endif
-// APEMOST_OB_HELPER_WAVE: the helper of the kSplit models as a ninth (LW + 5th) wavefront of the workgroup instead
-// of a duty of the candidate producers
-#ifndef APEMOST_OB_HELPER_WAVE
-#define APEMOST_OB_HELPER_WAVE 0
-#endif
-__host__ __device__ constexpr bool ob_has_helper_wave(int model) {
-    return APEMOST_OB_HELPER_WAVE != 0 && APEMOST_OB_SPLIT != 0 &&
-           (model % kVariantModel == APEMOST_MODEL_PULSE || model % kVariantModel == APEMOST_MODEL_PULSE_VROT);
+// HELPER: a ninth (LW + 5th) wavefront that computes the proposal's half of the threshold (the prior's logarithms);
+// for the models with a prior only, and only where the host finds one workgroup per CU (nine-wave workgroups do not
+// fit a CU twice under the kernel's register budget: ladders of 257-512 chains keep the eight-wave form).
+__host__ __device__ constexpr bool ob_can_help(int model) {
+    return model % kVariantModel == APEMOST_MODEL_PULSE || model % kVariantModel == APEMOST_MODEL_PULSE_VROT;
 }
-__host__ __device__ constexpr int ob_block(int model, int lw) { return (lw + 4 + (ob_has_helper_wave(model) ? 1 : 0)) * kWave; }
+__host__ __device__ constexpr int ob_block(int lw, bool helper) { return (lw + 4 + (helper ? 1 : 0)) * kWave; }
 
-template <int MODEL, int LW, bool LDS_DATA>
+template <int MODEL, int LW, bool LDS_DATA, bool HELPER = false>
 struct ObEngine {
 #ifdef APEMOST_STAMPS
     u64 seg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -152,8 +144,9 @@ struct ObEngine {
 #endif
     static constexpr int kLikThreads = LW * kWave;
     static constexpr int kProducers = 3;
-    static constexpr int kBlock = ob_block(MODEL, LW);
-    static constexpr bool kHelperWave = ob_has_helper_wave(MODEL); // the helper's duty in a wavefront of its own
+    static_assert(!HELPER || ob_can_help(MODEL), "a helper wavefront is for the models with a prior");
+    static constexpr int kBlock = ob_block(LW, HELPER);
+    static constexpr bool kHelperWave = HELPER; // the proposal's half of the threshold comes from a wavefront of its own
     static constexpr int kWide = LW < 8 ? 4 : 2;
     static constexpr int kShortChain = LW >= APEMOST_SHORT_CHAIN_WAVES ? 1 : LW >= APEMOST_EVEN_ODD_WAVES ? 2 : 0;
     static constexpr bool kVariants = MODEL >= kVariantModel; // see kVariantModel (pt_device.h)
@@ -202,7 +195,7 @@ struct ObEngine {
     __device__ __forceinline__ double *s_thr(int parity) const { return lds + kObThr + parity; }
     __device__ __forceinline__ double *s_thx(int parity) const { return lds + kObThx + parity; }
     __device__ __forceinline__ double *s_pri(int parity) const { return lds + kObPri + parity; }
-    static constexpr bool kSplit = ObThreshold<kBase>::kSplit;
+    static constexpr bool kSplit = HELPER; // S_max = X - Y (see ObThreshold)
     __device__ __forceinline__ int *s_flag(int parity) const { return (int *)(lds + kObFlag + parity); }
     // uniform by construction (every lane reads the same word): say so, the branch on it guards a barrier
     __device__ __forceinline__ bool redraw_pending(int parity) const {
@@ -366,10 +359,9 @@ struct ObEngine {
         if (j == 0)
             pipe_log = cand_log(pipe);
     }
-    // The helper's duty (kSplit), carried by whichever producer is in the phase with the shortest chain of
-    // its own (the Philox blocks: exactly one of the three at every step): decide the step that just ended
-    // like every other wave, take the prior of the proposal now in flight -- the row that decision selects
-    // -- and publish the proposal's half of S_max with it.  `parity` as in lik_step.
+    // The helper's duty (HELPER): decide the step that just ended like every other wave, take the prior of the
+    // proposal now in flight -- the row that decision selects -- and publish the proposal's half of S_max with it.
+    // `parity` as in lik_step.
     __device__ __forceinline__ void setup_helper(const DevArrays &d, const ChainShape &sh, int c) {
         consts = sh.consts;
         beta_all = d.beta()[c + 1];
@@ -379,14 +371,10 @@ struct ObEngine {
             m.set_lean(false);
         m.set_consts(consts);
     }
-#ifndef APEMOST_OB_HELPER_BOTH
-#define APEMOST_OB_HELPER_BOTH 1
-#endif
-    // APEMOST_OB_HELPER_BOTH: the priors of BOTH prepared rows, requested with the step's first LDS reads and
-    // taken side by side (Model::prior_two), the decision beside them, a select at the end -- the decision's
-    // LDS round trip, tree and compare (~300 ticks) leave the front of the logarithm's chain
+    // The priors of BOTH prepared rows, requested with the step's first LDS reads and taken side by side
+    // (Model::prior_two), the decision beside them, a select at the end: the decision's LDS round trip, tree and
+    // compare (~300 ticks) are not in front of the logarithm's chain.
     __device__ __forceinline__ void helper_step(int parity) {
-#if APEMOST_OB_HELPER_BOTH
         const double *ra = s_prop(parity, 0), *rr = s_prop(parity, 1);
         double part[LW];
         const double *sp = s_part(parity);
@@ -410,23 +398,9 @@ struct ObEngine {
             *s_thx(parity ^ 1) = x;
             *s_pri(parity ^ 1) = prior_k;
         }
-#else
-        const double sum = tree(parity);
-        const double limit = ObThreshold<kBase>::limit(*s_thx(parity), *s_thr(parity));
-        const double *row = s_prop(parity, sum < limit ? 0 : 1);
-        m.load_offset(row, n_par);
-        const double pr = m.prior_only(consts);
-        const double x = thr_fn.x_part(pr, m.offset());
-        if (lane == 0) {
-            *s_thx(parity ^ 1) = x;
-            *s_pri(parity ^ 1) = pr;
-        }
-#endif
     }
     __device__ __forceinline__ void producer_step(int parity) {
         if (pipe_phase == 0) {
-            if constexpr (kSplit && !kHelperWave)
-                helper_step(parity);
             pipe = cand_begin(pipe_tick);
             pipe_phase = 1;
         } else if (pipe_phase == 1) {

@@ -117,6 +117,13 @@ class HipSampler:
         capi.check(self.L.apemost_hip_launch_policy(self._h, C.byref(ob), C.byref(co), C.byref(mr)))
         return bool(ob.value), bool(co.value), mr.value
 
+    @property
+    def ob_helper(self):
+        """the one-barrier kernel runs with a helper wavefront (the prior of the proposal in flight off the owner)"""
+        ob = C.c_int32(0)
+        capi.check(self.L.apemost_hip_launch_policy(self._h, C.byref(ob), None, None))
+        return ob.value == 2
+
     def set_state(self, state, fields=None):
         v = state.view(fields) if fields else state.view()
         capi.check(self.L.apemost_hip_set_state(self._h, C.byref(v)))

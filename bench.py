@@ -191,14 +191,14 @@ def kernel_sources_sha1():
     return h.hexdigest()
 
 
-def expected_kernel(model, waves, lds, one_barrier, flags):
+def expected_kernel(model, waves, lds, one_barrier, flags, helper=False):
     """the instantiation the sampler's run phase launches, as rocprofv3 names it (pt_kernels.h launch_one;
     the proposal-law / RANDOMSWAP variants are MODEL + 8; workgroups of >= 4 waves of the two-phase kernel
     carry the candidate producers)"""
     variant = 8 if flags & (8 | 16 | 32) else 0
     b = "true" if lds else "false"
     if one_barrier:
-        return "apemost::pt_round_ob_kernel<%d, %d, %s>" % (model + variant, waves, b)
+        return "apemost::pt_round_ob_kernel<%d, %d, %s, %s>" % (model + variant, waves, b, "true" if helper else "false")
     return "apemost::pt_round_kernel<%d, %d, %s, %s>" % (model + variant, waves, b, "true" if waves >= 4 else "false")
 
 
@@ -391,7 +391,8 @@ def main():
     # the kernel sources have changed since that profile was taken (then the instruction count is that of an
     # older build of the same kernel: re-profile with tools/profile_config.sh).
     one_barrier = waves in (4, 8) and not (a.flags & 4)
-    kernel_name = expected_kernel(w.model, waves, lds, one_barrier, a.flags)
+    helper = one_barrier and s.ob_helper
+    kernel_name = expected_kernel(w.model, waves, lds, one_barrier, a.flags, helper)
     traffic_profiled = valu_insts = profile_src = profile_stale = None
     key = "%s/%d/%d/%d/%d/%s" % (w.name, n_local, w.n_data, n_swap, R, "nosamples" if a.no_samples else "samples")
     try:
@@ -415,7 +416,7 @@ def main():
         cus = props.multi_processor_count
     else:
         clock_hz, cus = 2400e6, dev_cus     # (MI355X_MICROARCH.md: 2.4 GHz peak engine clock)
-    waves_per_wg = waves + 4 if one_barrier else waves
+    waves_per_wg = waves + 4 + (1 if helper else 0) if one_barrier else waves
     cus_occupied = min(cus, n_local)
     simds_occupied = min(4 * cus, n_local * min(4, waves_per_wg))
     launch_s = launch_ms * 1e-3

@@ -221,8 +221,9 @@ int apemost_hip_synchronize(apemost_hip_sampler *s);
 /* the HIP stream (hipStream_t) every launch of this sampler goes to */
 int apemost_hip_stream(apemost_hip_sampler *s, void **stream);
 int apemost_hip_waves_per_chain(apemost_hip_sampler *s, int *waves, int *data_in_lds);
-/* how this sampler's stepping launches are issued as things stand: the one-barrier kernel or the
- * two-phase one, multi-round launches through hipLaunchCooperativeKernel or plain, and how many
+/* how this sampler's stepping launches are issued as things stand: the one-barrier kernel (1; 2: in its form
+ * with a helper wavefront, the models with a prior on ladders of at most one chain per CU) or the
+ * two-phase one (0), multi-round launches through hipLaunchCooperativeKernel or plain, and how many
  * rounds one launch may hold (1: the grid is not resident, a cooperative launch was refused, or a
  * hand-off timed out) */
 int apemost_hip_launch_policy(apemost_hip_sampler *s, int32_t *one_barrier, int32_t *cooperative, int32_t *max_rounds);

@@ -19,8 +19,9 @@ def _bench():
 
 def test_expected_kernel_names_are_the_ones_in_the_profile_registry():
     b = _bench()
-    assert b.expected_kernel(0, 4, True, True, 0) == "apemost::pt_round_ob_kernel<0, 4, true>"
-    assert b.expected_kernel(1, 8, True, True, 32) == "apemost::pt_round_ob_kernel<9, 8, true>"          # RANDOMSWAP: MODEL + 8
+    assert b.expected_kernel(0, 4, True, True, 0) == "apemost::pt_round_ob_kernel<0, 4, true, false>"
+    assert b.expected_kernel(1, 8, True, True, 32) == "apemost::pt_round_ob_kernel<9, 8, true, false>"   # RANDOMSWAP: MODEL + 8
+    assert b.expected_kernel(2, 4, True, True, 0, helper=True) == "apemost::pt_round_ob_kernel<2, 4, true, true>"   # with a helper wavefront
     assert b.expected_kernel(3, 1, False, False, 0) == "apemost::pt_round_kernel<3, 1, false, false>"
     assert b.expected_kernel(0, 4, True, False, 4) == "apemost::pt_round_kernel<0, 4, true, true>"       # two-phase, producers
     # every stepping-kernel entry of the registry names a kernel this function can produce
@@ -30,7 +31,8 @@ def test_expected_kernel_names_are_the_ones_in_the_profile_registry():
             for waves in (1, 2, 4, 6, 8):
                 for lds in (False, True):
                     for ob in (False, True):
-                        names.add(b.expected_kernel(model, waves, lds, ob, variant))
+                        for helper in (False, True):
+                            names.add(b.expected_kernel(model, waves, lds, ob, variant, helper))
     for e in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
         if "kernel" in e:
             assert e["kernel"].replace("void ", "").split("(")[0] in names, e["kernel"]

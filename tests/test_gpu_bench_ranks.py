@@ -56,7 +56,7 @@ def test_bench_starts_its_own_ranks_when_not_under_torchrun():
                           "--backend", "gloo", "--same-device", "--cpu-seconds", "0", "--launches-per-step", "3",
                           "--burn-in", "400"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     line = _check_two_rank_line(out)
-    assert line["roofline"]["kernel"] == "apemost::pt_round_ob_kernel<0, 4, true>"
+    assert line["roofline"]["kernel"] == "apemost::pt_round_ob_kernel<0, 4, true, false>"
 
 
 def test_bench_ends_every_rank_when_one_fails():

@@ -659,19 +659,22 @@ def test_circular_parameters_wrap_like_the_reference():
     s.close()
 
 
-@pytest.mark.parametrize("waves", [0, 8])
+@pytest.mark.parametrize("waves,helper", [(0, None), (8, None), (0, 0), (8, 0)])
 @pytest.mark.parametrize("flags", [0, capi.FLAG_RANDOMSWAP])
-def test_config4_shard_kernel_as_the_bench_launches_it_matches_oracle(flags, waves):
+def test_config4_shard_kernel_as_the_bench_launches_it_matches_oracle(flags, waves, helper, monkeypatch):
     """BASELINE config 4 as one GPU of eight sees it and as bench.py --config 4 launches it: pulse,
     256 chains x 1024 points, the geometry the engine chooses by itself (waves 0: four likelihood waves
-    + owner + three producers per chain since the pulse spectrum is taken over a common denominator,
-    the data vector in LDS; eight likelihood waves, the engine's choice of round 2 and still its choice
-    for more than three modes, asked for by name), n_swap 1 -- every step is a round, so the
-    pipeline of prepared proposals runs through round boundaries that are none and restarts only for
-    the two chains of a swap attempt --, 256 rounds in ONE launch placed by hipLaunchCooperativeKernel
-    (256 workgroups fit the occupancy figure but not the engine's cautious estimate), the pulse prior
-    computed one logarithm per lane.  Against the oracle: counters, ticks and swap counts bit-exact,
-    every recorded row to 1e-9; the same under -DRANDOMSWAP."""
+    + owner + three producers + the helper wavefront per chain -- one workgroup per CU --, the data vector in LDS;
+    eight likelihood waves, the engine's choice for more than three modes, asked for by name), n_swap 1 -- every
+    step is a round, so the pipeline of prepared proposals runs through round boundaries that are none and
+    restarts only for the two chains of a swap attempt --, 256 rounds in ONE launch, the pulse prior computed
+    one logarithm per lane (by the helper).  helper 0 (APEMOST_OB_HELPER=0): the kernels without the helper, the
+    owner takes the prior -- what ladders of 257-512 chains run; their twelve-wave form at 256 chains is placed by
+    hipLaunchCooperativeKernel (256 workgroups fit the occupancy figure but not the engine's cautious estimate).
+    Against the oracle: counters, ticks and swap counts bit-exact, every recorded row to 1e-9; the same under
+    -DRANDOMSWAP."""
+    if helper is not None:
+        monkeypatch.setenv("APEMOST_OB_HELPER", str(helper))
     torch = _torch()
     n_chain, n_rounds = 256, 256
     w = wl.pulse(n_data=1024, n_chain=n_chain)
@@ -680,9 +683,10 @@ def test_config4_shard_kernel_as_the_bench_launches_it_matches_oracle(flags, wav
     s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=404, flags=flags, waves_per_chain=waves)
     assert s.geometry == (waves or 4, True)
     one_barrier, cooperative, max_rounds = s.launch_policy
-    # (256 eight-wave workgroups are resident by the engine's own estimate, two per CU; the twelve-wave
-    # ones go through the runtime's placement)
-    assert one_barrier and cooperative == (waves == 8) and max_rounds >= n_rounds
+    # (with a helper: one workgroup per CU, resident as launched.  Without: 256 eight-wave workgroups are resident
+    # by the engine's own estimate, two per CU; the twelve-wave ones go through the runtime's placement)
+    assert s.ob_helper == (helper is None)
+    assert one_barrier and cooperative == (waves == 8 and helper == 0) and max_rounds >= n_rounds
     s.set_state(st)
     d = torch.zeros((n_rounds, 1, n_chain, w.n_par + 2), dtype=torch.float64, device="cuda")
     before = s.round[0]
