@@ -411,7 +411,7 @@ void pt_round_kernel(const RoundArgs a) {
 #define OB_STAMP_END ob_busy += __builtin_amdgcn_s_memtime() - ob_t0
 #define OB_STAMP_FLUSH                                                                            \
     if (blockIdx.x == 0 && e.lane == 0)                                                           \
-    atomicAdd(&g_stamps[e.hw], ob_busy)
+    atomicAdd(&g_stamps[e.is_helper() ? 14 : e.hw], ob_busy) /* (slots 8-13: the owner's segments when LW = 4) */
 #else
 #define OB_STAMP_DECL
 #define OB_STAMP_BEGIN
@@ -446,11 +446,15 @@ __device__ __forceinline__ u64 rounds_restarting(const E &e, const RoundArgs &a,
 }
 
 template <int MODEL, int LW, bool LDS_DATA, bool HELPER>
-__global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_round_ob_kernel(const RoundArgs a) {
+__global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_per_eu(ob_waves_per_eu(LW, HELPER)))) void pt_round_ob_kernel(const RoundArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA, HELPER> e;
     const int c = blockIdx.x;
     e.setup_common(a.d, a.sh, c, lds);
+#if APEMOST_OB_HELPER_SIMD
+    if (HELPER && e.hw > LW + 3 && !e.is_helper())
+        return; // (placeholders: see APEMOST_OB_HELPER_SIMD)
+#endif
     OB_STAMP_DECL;
     // bit r % 64: the pipeline restarts at the start of round r (parity 0, the owner's first proposal
     // from the current point, one barrier more): at the launch's start and where a swap attempt moves
@@ -462,6 +466,16 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
             e.make_set(e.tick + (u64)e.hw); // the first two ticks' candidates, by waves with nothing else to do yet
         __syncthreads();
         e.cache_rows();
+        // With a helper wavefront SIMD 0 holds three waves -- likelihood wave 0, the owner, the helper -- and that
+        // likelihood wave is the one the step waits for (busy 1600 of 1580 ticks, the three others 1400, the owner
+        // 1440, the helper 1490: profiles/r04_pulse_helper_wave.txt): it goes first on its SIMD.  Config 4 2.69 ->
+        // 2.71e8 steps/s whatever the owner's priority.  Without the helper the owner is the last wave and this
+        // costs 20 % (config 2: 2.14 -> 1.69e8).
+#ifndef APEMOST_LIK0_PRIO
+#define APEMOST_LIK0_PRIO 3
+#endif
+        if (HELPER && e.hw == 0)
+            __builtin_amdgcn_s_setprio(APEMOST_LIK0_PRIO);
         int p = 0; // parity of the step about to start
         for (unsigned r = 0; r < a.n_rounds; r++) {
             if ((r & 63) == 0)
@@ -507,6 +521,9 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
     } else if (e.is_helper()) {
         // (HELPER) the helper alone: the barrier sequence of a producer, helper_step per step
         if constexpr (decltype(e)::kHelperWave) {
+#ifdef APEMOST_HELPER_PRIO
+            __builtin_amdgcn_s_setprio(APEMOST_HELPER_PRIO); // (experiment, round 4: tools/experiments/r04_session14.sh)
+#endif
             e.setup_lanes(a.sh, c);
             e.setup_helper(a.d, a.sh, c);
             __syncthreads();
@@ -519,13 +536,16 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
                     __syncthreads();
                 }
                 for (unsigned s = 0; s < a.n_steps; s++) {
+                    OB_STAMP_BEGIN;
                     if (e.redraw_pending(p))
                         __syncthreads();
                     e.helper_step(p);
+                    OB_STAMP_END;
                     __syncthreads();
                     p ^= 1;
                 }
             }
+            OB_STAMP_FLUSH;
         }
     } else {
         // the others wait for this wave at every barrier and it has little to issue: let it go first
@@ -999,12 +1019,16 @@ void pt_calibrate_kernel(const CalibArgs a) {
 // parameter vectors as ever.  The proposal of parameter p+1 does not depend on the outcome of
 // parameter p's step, only the rest of the vector does, so both variants carry the same attempt.
 template <int MODEL, int LW, bool LDS_DATA, bool HELPER>
-__global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_per_eu(APEMOST_OB_WAVES_PER_EU))) void pt_calibrate_ob_kernel(const CalibArgs a) {
+__global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_per_eu(ob_waves_per_eu(LW, HELPER)))) void pt_calibrate_ob_kernel(const CalibArgs a) {
     extern __shared__ __align__(16) double lds[];
     ObEngine<MODEL, LW, LDS_DATA, HELPER> e;
     const int slot = a.list[blockIdx.x];
     const int c = a.first + slot;
     e.setup_common(a.d, a.sh, c, lds);
+#if APEMOST_OB_HELPER_SIMD
+    if (HELPER && e.hw > LW + 3 && !e.is_helper())
+        return; // (placeholders: see APEMOST_OB_HELPER_SIMD)
+#endif
     volatile int *s_steps = (volatile int *)(lds + kObCtl); // word 0 (word 2 is the fail flag)
     if (e.is_lik()) {
         e.setup_lik(a.d, a.sh, c);
@@ -1012,6 +1036,8 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
             e.make_set(e.tick + (u64)e.hw);
         __syncthreads();
         e.cache_rows();
+        // (likelihood wave 0 at a priority of its own, as in the round kernel: the calibration 0.32 -> 0.34 s at 3, no
+        // change at 2 -- tools/experiments/r04_session17.sh -- not taken)
         for (;;) {
             __syncthreads(); // the block's opening barrier
             const int n_steps = __builtin_amdgcn_readfirstlane(*s_steps);

@@ -134,7 +134,23 @@ struct ObThreshold<APEMOST_MODEL_PULSE_VROT> : ObThreshold<APEMOST_MODEL_PULSE> 
 __host__ __device__ constexpr bool ob_can_help(int model) {
     return model % kVariantModel == APEMOST_MODEL_PULSE || model % kVariantModel == APEMOST_MODEL_PULSE_VROT;
 }
-__host__ __device__ constexpr int ob_block(int lw, bool helper) { return (lw + 4 + (helper ? 1 : 0)) * kWave; }
+// (experiment, round 4: APEMOST_OB_HELPER_SIMD = s puts s wavefronts that end at once between the producers and the
+// helper, so that the helper -- wave w runs on SIMD w mod 4 -- lands on SIMD s instead of beside likelihood wave 0 and the owner)
+#ifndef APEMOST_OB_HELPER_SIMD
+#define APEMOST_OB_HELPER_SIMD 0
+#endif
+__host__ __device__ constexpr int ob_block(int lw, bool helper) { return (lw + 4 + (helper ? 1 + APEMOST_OB_HELPER_SIMD : 0)) * kWave; }
+
+// Register budget of the one-barrier kernels: waves per SIMD the compiler must leave room for.  Eight- and twelve-wave
+// workgroups share a CU two by two (4 per SIMD: 128 registers); the nine-wave ones (four likelihood waves + helper)
+// have a CU to themselves, three waves on SIMD 0: 168 registers, the calibration kernel stops spilling (12-13
+// registers at 128) -- config 4 2.668 -> 2.697e8 steps/s, calibration 0.328 -> 0.320 s (profiles/r04_pulse_helper_wave.txt).
+#ifndef APEMOST_OB_HELPER_EU
+#define APEMOST_OB_HELPER_EU 3
+#endif
+__host__ __device__ constexpr int ob_waves_per_eu(int lw, bool helper) {
+    return helper && lw == 4 ? APEMOST_OB_HELPER_EU : APEMOST_OB_WAVES_PER_EU;
+}
 
 template <int MODEL, int LW, bool LDS_DATA, bool HELPER = false>
 struct ObEngine {
@@ -160,7 +176,7 @@ struct ObEngine {
     __device__ __forceinline__ bool is_lik() const { return hw < LW; }
     __device__ __forceinline__ bool is_owner() const { return hw == LW; }
     __device__ __forceinline__ bool is_producer() const { return hw > LW && hw <= LW + kProducers; }
-    __device__ __forceinline__ bool is_helper() const { return kHelperWave && hw == LW + kProducers + 1; }
+    __device__ __forceinline__ bool is_helper() const { return kHelperWave && hw == LW + kProducers + 1 + APEMOST_OB_HELPER_SIMD; }
 
     int n_par, n_data;
     int Q, grp, qidx, n_cand_lanes;

@@ -83,4 +83,5 @@ def main():
                 print("  loop %06x..%06x: %s" % (target, addr, c))
 
 
-main()
+if __name__ == "__main__":
+    main()

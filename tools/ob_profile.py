@@ -42,6 +42,8 @@ def main():
     for hw in range(waves + 4):
         role = "likelihood" if hw < waves else "owner" if hw == waves else "producer"
         print("   wave %2d %-10s busy %7.0f" % (hw, role, out[hw] / n_steps))
+    if s.ob_helper:
+        print("   wave %2d %-10s busy %7.0f" % (waves + 4, "helper", out[14] / n_steps))
     if waves == 4:
         names = ["LDS batch, partial sums, decision", "finish, counters, best point, sample row", "the proposal in flight (choose)",
                  "next candidates, both prepared proposals", "the prior of the proposal in flight", "threshold, flags"]
