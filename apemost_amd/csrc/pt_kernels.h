@@ -405,6 +405,9 @@ void pt_round_kernel(const RoundArgs a) {
 // Diagnostic build (-DAPEMOST_STAMPS): per wave of workgroup 0, the cycles between leaving a step's
 // barrier and arriving at the next one (g_stamps[wave]); g_stamps[15] = whole steps of the owner,
 // barrier to barrier.  Tells which role the others wait for.
+#ifndef APEMOST_MERGED_ALL
+#define APEMOST_MERGED_ALL 0 // (experiment: the sine models' round kernel through attempts2() too; see ObEngine::owner_publish)
+#endif
 #ifdef APEMOST_STAMPS
 #define OB_STAMP_DECL u64 ob_busy = 0, ob_t0 = 0, ob_total = 0, ob_prev = 0
 #define OB_STAMP_BEGIN ob_t0 = __builtin_amdgcn_s_memtime()
@@ -495,8 +498,6 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
         OB_STAMP_FLUSH;
     } else if (e.is_producer()) {
         e.setup_lanes(a.sh, c);
-        if constexpr (decltype(e)::kSplit)
-            e.setup_helper(a.d, a.sh, c);
         e.producer_prologue();
         __syncthreads();
         int p = 0;
@@ -509,10 +510,19 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
             }
             for (unsigned s = 0; s < a.n_steps; s++) {
                 OB_STAMP_BEGIN;
+#if defined(APEMOST_STAMPS) && defined(APEMOST_STAMP_PHASES)
+                const int ph = e.pipe_phase; // (the first producer's step by phase: slots 8-10 instead of the owner's segments)
+#endif
+                // (the redraw flag requested first and looked at behind the phase's work -- the candidates do not depend
+                // on it, only the barrier count does -- changes nothing: 2.131 vs 2.132e8 at config 2, session 20)
                 if (e.redraw_pending(p))
                     __syncthreads();
                 e.producer_step(p);
                 OB_STAMP_END;
+#if defined(APEMOST_STAMPS) && defined(APEMOST_STAMP_PHASES)
+                if (blockIdx.x == 0 && e.lane == 0 && e.hw == LW + 1)
+                    atomicAdd(&g_stamps[8 + ph], __builtin_amdgcn_s_memtime() - ob_t0);
+#endif
                 __syncthreads();
                 p ^= 1;
             }
@@ -625,11 +635,11 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
                 // nobody waits for the owner's whole program (the two-step look-ahead of DESIGN.md 9 would
                 // give it that slack).  The redraw flag is never set in this build.
                 __syncthreads();
-                e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior>(p, nx);
+                e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior || APEMOST_MERGED_ALL>(p, nx);
                 e.tick++;
                 OB_STAMP_END;
 #else
-                e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior>(p, nx);
+                e.template owner_publish<Model<MODEL % kVariantModel>::kHasPrior || APEMOST_MERGED_ALL>(p, nx);
                 e.tick++;
                 OB_STAMP_END;
                 __syncthreads();
@@ -650,7 +660,11 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
 #ifdef APEMOST_STAMPS
         if (blockIdx.x == 0 && e.lane == 0) {
             atomicAdd(&g_stamps[15], ob_total);
+#ifndef APEMOST_STAMP_PHASES
             if (LW == 4) // (slots 8..13 are free with eight waves per workgroup)
+#else
+            if (false)
+#endif
                 for (int i = 0; i < 6; i++)
                     atomicAdd(&g_stamps[8 + i], e.seg_acc[i]);
         }
@@ -1052,8 +1066,6 @@ __global__ __launch_bounds__(ob_block(LW, HELPER)) __attribute__((amdgpu_waves_p
         }
     } else if (e.is_producer()) {
         e.setup_lanes(a.sh, c);
-        if constexpr (decltype(e)::kSplit)
-            e.setup_helper(a.d, a.sh, c);
         e.producer_prologue();
         __syncthreads();
         for (;;) {

@@ -168,6 +168,10 @@ struct ObEngine {
     static constexpr bool kVariants = MODEL >= kVariantModel; // see kVariantModel (pt_device.h)
     static constexpr int kBase = MODEL % kVariantModel;
     static constexpr bool kSine = kBase == APEMOST_MODEL_SIMPLESIN || kBase == APEMOST_MODEL_SINE3;
+#ifndef APEMOST_PHILOX_MERGED
+#define APEMOST_PHILOX_MERGED 2 // 0: never, 1: always, 2: the sine models
+#endif
+    static constexpr bool kMergedPhilox = APEMOST_PHILOX_MERGED == 1 || (APEMOST_PHILOX_MERGED == 2 && kSine);
 
     // ---- identity ----
     int lane, hw;  // lane, hardware wave index in the workgroup
@@ -306,28 +310,54 @@ struct ObEngine {
         double y, v; // attempt lanes: second polar coordinate and r^2; lane 63: (unused, the uniform)
         bool ok;
     };
+    // ONE Philox evaluation for the whole wavefront: the attempt lanes' blocks and the accept uniform's (lane 63)
+    // differ in their address only.  (Until round 4 each had its own call under its own branch, and a wavefront runs
+    // the two sides of a divergent branch one after the other: twice the ten rounds, 43 v_mad_u64_u32 and 103 v_xor
+    // in the producers' step -- whose Philox phase, 1313-1344 ticks, was as long as the owner's step at config 2.)
     __device__ __forceinline__ Half cand_begin(u64 t) const {
-        Half h;
-        h.y = h.v = 0;
-        h.ok = false;
-        if (cand()) {
-            const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)grp, (t << kTickShift) | (u64)qidx);
-            const double x = -1 + 2 * u32_to_uniform(b.x);
-            h.y = -1 + 2 * u32_to_uniform(b.y);
-            h.v = x * x + h.y * h.y;
-            h.ok = b.x != 0 && b.y != 0 && !(h.v > 1.0 || h.v == 0);
+        if constexpr (kMergedPhilox) {
+            Half h;
+            const bool uni = lane == 63;
+            const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)(uni ? n_par : grp),
+                                         (t << kTickShift) | (u64)(uni ? 0 : qidx));
+            const double u0 = u32_to_uniform(b.x);
+            const double x = -1 + 2 * u0;
+            double y = -1 + 2 * u32_to_uniform(b.y);
+            double v = x * x + y * y;
+            bool ok = b.x != 0 && b.y != 0 && !(v > 1.0 || v == 0);
             if (kVariants && proposal_law(circular) != kProposalGaussian) { // uniform; see Engine::cand_begin
-                const double x0 = u32_to_uniform(b.x);
                 const bool logistic = proposal_law(circular) == kProposalLogistic;
-                h.y = x0;
-                h.v = logistic ? x0 / (1 - x0) : 1.0;
-                h.ok = logistic ? b.x != 0 : true;
+                y = u0;
+                v = logistic ? u0 / (1 - u0) : 1.0;
+                ok = logistic ? b.x != 0 : true;
             }
-        } else if (lane == 63) {
-            const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)n_par, t << kTickShift);
-            h.v = u32_to_uniform(b.x);
+            h.y = cand() ? y : 0.0;
+            h.v = cand() ? v : uni ? u0 : 0.0;
+            h.ok = cand() && ok;
+            return h;
+        } else {
+            Half h;
+            h.y = h.v = 0;
+            h.ok = false;
+            if (cand()) {
+                const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)grp, (t << kTickShift) | (u64)qidx);
+                const double x = -1 + 2 * u32_to_uniform(b.x);
+                h.y = -1 + 2 * u32_to_uniform(b.y);
+                h.v = x * x + h.y * h.y;
+                h.ok = b.x != 0 && b.y != 0 && !(h.v > 1.0 || h.v == 0);
+                if (kVariants && proposal_law(circular) != kProposalGaussian) { // uniform; see Engine::cand_begin
+                    const double x0 = u32_to_uniform(b.x);
+                    const bool logistic = proposal_law(circular) == kProposalLogistic;
+                    h.y = x0;
+                    h.v = logistic ? x0 / (1 - x0) : 1.0;
+                    h.ok = logistic ? b.x != 0 : true;
+                }
+            } else if (lane == 63) {
+                const uint4 b = philox_block(seed, g * APEMOST_HIP_STREAMS_PER_CHAIN + (u64)n_par, t << kTickShift);
+                h.v = u32_to_uniform(b.x);
+            }
+            return h;
         }
-        return h;
     }
     // ln r^2 for the attempt lanes, ln u for lane 63 (one field for both: a select between two
     // fields of a struct turns into a computed address and the whole engine into scratch memory)
@@ -694,6 +724,10 @@ struct ObEngine {
         __builtin_amdgcn_wave_barrier();
         if (lane < n_par)
             s_prop(0, 0)[lane] = row[lane];
+#ifdef APEMOST_EXP_NO_ATTEMPTS
+        if (lane < n_par)
+            s_prop(1, 0)[lane] = s_prop(1, 1)[lane] = row[lane];
+#endif
         if (lane == 0) {
             *s_thr(0) = kSplit ? 0.0 : __builtin_inf();
             if constexpr (kSplit)
@@ -818,12 +852,18 @@ struct ObEngine {
         next_y = nx.x;
         next_s = nx.y;
         // the two proposals of the next step: from the proposal in flight, from the current point
+#ifdef APEMOST_EXP_NO_ATTEMPTS
+        // TIMING ONLY (results are garbage; tools/experiments/r04_session18.sh, 20): what the step costs when somebody
+        // else prepares the proposals, before that somebody's own cost
+        fail_a = fail_r = 0;
+#else
         if constexpr (MERGED) {
             attempts2(par_val, cur, next_y, next_s, s_prop(next, 0), s_prop(next, 1), which_next, fail_a, fail_r);
         } else {
             fail_a = attempts(par_val, next_y, next_s, s_prop(next, 0), which_next);
             fail_r = attempts(cur, next_y, next_s, s_prop(next, 1), which_next);
         }
+#endif
         OB_SEG(3); // next candidates, both prepared proposals
 #if defined(APEMOST_OWNER_PRIO_PHASE) && APEMOST_OWNER_PRIO_PHASE == 1
         __builtin_amdgcn_s_setprio(0);

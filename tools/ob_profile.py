@@ -44,7 +44,11 @@ def main():
         print("   wave %2d %-10s busy %7.0f" % (hw, role, out[hw] / n_steps))
     if s.ob_helper:
         print("   wave %2d %-10s busy %7.0f" % (waves + 4, "helper", out[14] / n_steps))
-    if waves == 4:
+    if os.environ.get("APEMOST_STAMP_PHASES"):
+        # a twin built with -DAPEMOST_STAMP_PHASES: the first producer's step by phase (each phase every third step)
+        for i, nm in enumerate(["Philox blocks, polar test", "logarithm", "division, square root, store"]):
+            print("   producer phase %d (%s): %7.0f ticks" % (i, nm, out[8 + i] / (n_steps / 3.0)))
+    elif waves == 4:
         names = ["LDS batch, partial sums, decision", "finish, counters, best point, sample row", "the proposal in flight (choose)",
                  "next candidates, both prepared proposals", "the prior of the proposal in flight", "threshold, flags"]
         print("   the owner's step in segments (ticks between the points it reaches):")
