@@ -1095,12 +1095,13 @@ extern "C" int apemost_hip_get_round(apemost_hip_sampler *s, uint64_t *round, in
 // The one-barrier step with a helper wavefront (pt_onebarrier.h, HELPER): the models with a prior, where every
 // workgroup of the launch has a CU to itself -- nine (thirteen) wavefronts; two such workgroups on a CU were not
 // measured to gain (ladders of 257-512 chains keep the eight-wave form and its two workgroups per CU).
-// APEMOST_OB_HELPER=0/1 overrides the choice (A/B runs, tests).
+// APEMOST_OB_HELPER=0 switches it off (A/B runs, tests); it never runs on ladders of more than one chain per CU,
+// whose nine-wave grids would not be resident.
 static bool ob_wants_helper(const apemost_hip_sampler *s, int n_chains) {
     if (!ob_can_help(s->kmodel))
         return false;
-    if (const char *env = getenv("APEMOST_OB_HELPER"))
-        return atoi(env) != 0;
+    if (const char *env = getenv("APEMOST_OB_HELPER")) // (0 switches it off; 1 is the default where it may run at all)
+        return atoi(env) != 0 && n_chains <= s->cus;
     return n_chains <= s->cus;
 }
 

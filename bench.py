@@ -179,13 +179,15 @@ def cpu_baseline(w, st_template, n_swap, seconds):
 
 
 def kernel_sources_sha1():
-    """sha1 over the kernel sources (csrc/*.h, *.hip): tools/summarize_profile.py stores it with the counters it
-    registers in profiles/pmc_traffic.json, so that a line can say whether they belong to this build"""
+    """sha1 over the kernel sources (csrc/*.h and the kernels' translation unit apemost_model.hip -- not
+    apemost_hip.hip, the host side of the ABI, whose changes leave every kernel's code object what it was):
+    tools/summarize_profile.py stores it with the counters it registers in profiles/pmc_traffic.json, so that a line can
+    say whether they belong to this build"""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "apemost_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip")):
+        if f.endswith((".h", ".hip")) and f != "apemost_hip.hip":
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()

@@ -46,6 +46,29 @@ def test_calibration_matches_oracle(name, waves):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["pulse", "pulse_vrot"])
+@pytest.mark.parametrize("waves", [4, 8])
+def test_one_barrier_calibration_without_the_helper_wavefront_matches_oracle(name, waves, monkeypatch):
+    """pt_calibrate_ob_kernel<..., HELPER = false> for the models with a prior: what ladders of more than one chain per CU
+    calibrate in (257-512 chains), where the owner computes the proposal's prior itself.  Small ladders get the helper
+    by default (the test above); APEMOST_OB_HELPER=0 selects the other kernel, which must give the same chains."""
+    monkeypatch.setenv("APEMOST_OB_HELPER", "0")
+    w = small_workloads()[name]
+    n_chain = 4
+    st, lad, rng = make_pair(w, n_chain, seed=5, init_prob=True)
+    s = HipSampler(w.model, w.n_par, n_chain, w.data, seed=5, waves_per_chain=waves)
+    assert s.geometry[0] == waves and s.launch_policy[0] and not s.ob_helper
+    s.set_state(st)
+    dcfg, ocfg = _cfgs()
+    status, iters = s.markov_chain_calibrate(0, n_chain, dcfg)
+    dev = s.get_state()
+    for c in range(n_chain):
+        st_o, it_o = orc.markov_chain_calibrate(lad, rng, c, ocfg)
+        assert status[c] == st_o and iters[c] == it_o, (c, status[c], st_o, iters[c], it_o)
+    assert_match(dev, lad, rng, what="calibrate %s waves=%d without helper" % (name, waves))
+    s.close()
+
+
 @pytest.mark.parametrize("waves", [4, 8])
 def test_calibration_with_rows_in_registers_matches_oracle(waves):
     """BASELINE config 2's shape: 1024 points = one pass of the interleaved loop, so every lane keeps
